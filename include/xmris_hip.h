@@ -1,0 +1,106 @@
+/* xmris_hip.h -- C ABI of libxmris_hip.so: the MI355X (gfx950) backend of the xmris `.xmr`
+ * spectral hot path  zero_fill -> apodize_exp -> to_spectrum (ortho FFT + fftshift) -> autophase.
+ *
+ * The reference (andrewendlinger/xmris v0.6.1) is pure Python and has no FFI; the seam these
+ * entry points replace is the ndarray boundary inside `src/xmris/processing/*.py`
+ * (`da.values` + `da.get_axis_num(dim)` on the way in, `da.copy(data=...)` on the way out).
+ * Each function cites the reference statement it stands in for.  All metadata (dims, coords,
+ * attrs, validation, exceptions) stays in the Python host layer (`xmris_amd/`).
+ *
+ * Conventions
+ *  - Plain C types only.  All array pointers are DEVICE pointers owned by the caller; the
+ *    library never frees or retains them.  `stream` is a hipStream_t passed as void* (NULL =
+ *    the default stream).  Calls are asynchronous on that stream; nothing synchronises.
+ *  - Layout: `n_batch` spectra, C-contiguous, FID / frequency axis last, interleaved complex
+ *    (re, im).  dtype XM_C64 = 2 x float32, XM_C128 = 2 x float64.
+ *  - Return value: 0 on success, negative xm_status on failure (no exceptions, no aborts);
+ *    `xm_last_error_string()` describes the last failure on the calling thread.
+ *  - Twiddle / chirp tables are computed in fp64 on the host, rounded once to the storage
+ *    precision and cached per (length, dtype, device) inside the library (mutex-guarded);
+ *    `xm_clear_cache()` frees them.  Reentrant otherwise.
+ */
+#ifndef XMRIS_HIP_H
+#define XMRIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { XM_C64 = 0, XM_C128 = 1 } xm_dtype;
+
+typedef enum {
+  XM_OK = 0,
+  XM_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad dtype/flag combination   */
+  XM_ERR_UNSUPPORTED_N = -2, /* transform length has no in-LDS plan (see xm_fft_supported) */
+  XM_ERR_HIP = -3,           /* a HIP runtime call failed; see xm_last_error_string()      */
+  XM_ERR_NO_DEVICE = -4
+} xm_status;
+
+/* xm_fft1d_batched / xm_pipeline_fused flags */
+#define XM_FFT_INVERSE 1u   /* e^{+2 pi i km/N}  (np.fft.ifftn, fourier.py:210)             */
+#define XM_FFT_ORTHO 2u     /* scale 1/sqrt(N)   (norm="ortho", fourier.py:153)             */
+#define XM_FFT_SHIFT_IN 4u  /* roll the INPUT by (N+1)/2 first  (ifftshift, fourier.py:57)  */
+#define XM_FFT_SHIFT_OUT 8u /* roll the OUTPUT by N/2 afterwards (fftshift, fourier.py:31)  */
+
+int xm_version(void); /* 10000*major + 100*minor + patch */
+const char* xm_last_error_string(void);
+int xm_clear_cache(void);
+/* 1 if a length-n transform of `dtype` has an in-LDS plan (direct or Bluestein), else 0. */
+int xm_fft_supported(int n, int dtype);
+/* Build (and cache) the tables for length n so that later calls do no allocation. */
+int xm_plan_prepare(int n, int dtype);
+
+/* A1  zero_fill  (processing/fid.py:251  da.pad(..., constant_values=0)).
+ * out[b, j] = in[b, j - pad_left] for pad_left <= j < pad_left + n_in, else 0.  Bit-exact copy. */
+int xm_zero_fill(const void* in, void* out, int64_t n_batch, int n_in, int n_out, int pad_left,
+                 int dtype, void* stream);
+
+/* A2  apodize  (processing/fid.py:139  da * weight).  out[b, j] = in[b, j] * window[j];
+ * `window` is n real values of the storage precision (host computes exp(-pi*lb*t), fid.py:136).
+ * in == out allowed. */
+int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, int n, int dtype,
+               void* stream);
+
+/* A3/A4/A5  fft / ifft / fftshift folded  (processing/fourier.py:153, 210, 31, 57).
+ * out[b, (m + s_out) mod n] = scale * sum_k in[b, (k - s_in) mod n] * e^{-+2 pi i k m / n}. */
+int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype,
+                     void* stream);
+
+/* A4 alone  (fourier.py:31-32, 57-58  da.roll).  out[b, (j + shift) mod n] = in[b, j]. */
+int xm_roll(const void* in, void* out, int64_t n_batch, int n, int shift, int dtype, void* stream);
+
+/* A8  phase apply  (processing/phasing.py:73  da * exp(1j*phase_array)).
+ * out[b, j] = in[b, j] * phase_table[j]  (n complex values; host computes e^{i phi}, phasing.py:62-69).
+ * in == out allowed. */
+int xm_phase_apply(const void* in, void* out, const void* phase_table, int64_t n_batch, int n,
+                   int dtype, void* stream);
+
+/* A6  per-spectrum max |X|^2 and its first index  (first half of phasing.py:229).
+ * absmax2[b] (real, storage precision) and argidx[b] (int32) for every spectrum of an existing array. */
+int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_t* argidx, int dtype,
+                   void* stream);
+
+/* A6  global arg-max  (phasing.py:229  np.argmax(np.abs(values)), first maximum in C order).
+ * Reduces the per-spectrum pairs: out_max2[0] = max_b absmax2[b], out_flat[0] = b*n + argidx[b]
+ * of the first such b.  Both outputs are device scalars. */
+int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch, int n, void* out_max2,
+                     int64_t* out_flat, int dtype, void* stream);
+
+/* The fused hot path, one launch:
+ *   z[j]   = (pad_left <= j < pad_left + n_in) ? in[b, j - pad_left] * window[j] : 0   (A1+A2)
+ *   X      = FFT_n_out(z) * scale, optionally rolled                                    (A3+A4)
+ *   absmax2[b], argidx[b] = max |X|^2 and its first index (after the roll)              (A6)
+ *   out[b, k] = X[k] * phase_table[k]                                                   (A8)
+ * `window` (n_out reals), `phase_table` (n_out complex), `out`, `absmax2`, `argidx` may each be
+ * NULL to skip that part (out == NULL -> the arg-max pre-pass, nothing is written but the pairs).
+ * `in_row_stride` = elements between consecutive input spectra (>= n_in). */
+int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const void* window,
+                      const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left,
+                      unsigned flags, void* absmax2, int32_t* argidx, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMRIS_HIP_H */

@@ -1,0 +1,218 @@
+"""GPU parity tests: every entry point of libxmris_hip.so (through the C ABI) against the CPU
+oracle on the same seeded inputs.  Integer/index work is bit-exact; floating point is compared
+with the tolerance the north-star states (1e-5 relative to the spectrum's largest magnitude for
+complex64, 1e-12 for complex128)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"complex64": 1e-5, "complex128": 1e-12}
+# observed fp32 error is ~2e-7; keep a tighter regression guard as well
+TIGHT = {"complex64": 2e-6, "complex128": 1e-13}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    from xmris_amd import device
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device (no CPU fallback exists)"
+    return device
+
+
+def _rand(shape, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+def _relerr(got, ref):
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
+MIXED = [384, 768, 1536, 3072, 6144, 640, 1280, 2560, 5120]
+BLUESTEIN = [3, 5, 7, 17, 100, 1000, 1531, 2000, 2049, 4095]
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n", POW2 + MIXED + BLUESTEIN + [16384])
+def test_fft_matches_numpy(dev, oracle, n, dtype):
+    if n == 16384 and dtype == "complex128":
+        assert not dev.fft_supported(n, complex128=True)
+        return
+    nb = 7 if n > 64 else 37  # ragged vs. spectra-per-workgroup
+    x = _rand((nb, n), dtype, seed=n)
+    ref = oracle.fft_values(x.astype(np.complex128), 1)
+    got = dev.fft(dev.to_device(x), 1).cpu().numpy()
+    assert got.dtype == np.dtype(dtype)
+    tol = TIGHT[dtype] * (4 if n in BLUESTEIN else 1)
+    assert _relerr(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n", [7, 8, 256, 1000, 1536, 4096])
+def test_fft_flags(dev, oracle, n, dtype):
+    x = _rand((5, n), dtype, seed=3)
+    xd = dev.to_device(x)
+    x128 = x.astype(np.complex128)
+    tol = TIGHT[dtype] * 4
+    # to_spectrum = fftshift(fft)
+    ref = oracle.to_spectrum_values(x128, 1)
+    assert _relerr(dev.fft(xd, 1, shift_out=True).cpu().numpy(), ref) < tol
+    # to_fid = ifft(ifftshift)   (fid.py:73-77)
+    ref = np.fft.ifftn(np.roll(x128, (n + 1) // 2, axis=1), axes=(1,), norm="ortho")
+    assert _relerr(dev.fft(xd, 1, inverse=True, shift_in=True).cpu().numpy(), ref) < tol
+    # fftc / ifftc  (fourier.py:258-264, 292-298)
+    ref = np.roll(np.fft.fftn(np.roll(x128, (n + 1) // 2, axis=1), axes=(1,), norm="ortho"), n // 2, axis=1)
+    assert _relerr(dev.fft(xd, 1, shift_in=True, shift_out=True).cpu().numpy(), ref) < tol
+    ref = np.roll(np.fft.ifftn(np.roll(x128, (n + 1) // 2, axis=1), axes=(1,), norm="ortho"), n // 2, axis=1)
+    assert _relerr(dev.fft(xd, 1, inverse=True, shift_in=True, shift_out=True).cpu().numpy(), ref) < tol
+    # un-normalised forward / 1/N inverse
+    assert _relerr(dev.fft(xd, 1, ortho=False).cpu().numpy(), np.fft.fft(x128, axis=1)) < tol
+    assert _relerr(dev.fft(xd, 1, inverse=True, ortho=False).cpu().numpy(), np.fft.ifft(x128, axis=1)) < tol
+
+
+def test_fft_axis_and_roundtrip(dev, oracle):
+    x = _rand((6, 256, 5), "complex128", seed=11)
+    xd = dev.to_device(x)
+    got = dev.fft(xd, 1, shift_out=True)
+    assert _relerr(got.cpu().numpy(), oracle.to_spectrum_values(x, 1)) < 1e-13
+    back = dev.fft(got, 1, inverse=True, shift_in=True)  # to_fid(to_spectrum(x)) == x
+    np.testing.assert_allclose(back.cpu().numpy(), x, atol=1e-10)  # fid_transformations.md:151-157
+    one = dev.fft(dev.to_device(_rand((4, 1), "complex64")), 1)
+    assert one.shape == (4, 1)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_zero_fill_bit_exact(dev, oracle, dtype):
+    x = _rand((9, 100), dtype, seed=5)
+    xd = dev.to_device(x)
+    for target, position in [(512, "end"), (257, "end"), (128, "symmetric"), (131, "symmetric")]:
+        ref, pad_left = oracle.zero_fill_values(x, 1, target, position)
+        got = dev.zero_fill(xd, 1, target, pad_left).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    # another axis (k-space style, zero_fill.md:257-295)
+    y = _rand((32, 6), dtype, seed=6)
+    ref, pad_left = oracle.zero_fill_values(y, 0, 128, "symmetric")
+    np.testing.assert_array_equal(dev.zero_fill(dev.to_device(y), 0, 128, pad_left).cpu().numpy(), ref)
+
+
+def test_apodize_and_phase_complex128_bit_exact(dev, oracle):
+    n = 777
+    x = _rand((4, n), "complex128", seed=8)
+    t = np.arange(n) * 2e-4 + 1e-3
+    w = oracle.exp_window(t, 5.0)
+    got = dev.apodize(dev.to_device(x), 1, w).cpu().numpy()
+    np.testing.assert_array_equal(got, x * w)  # complex x real: same two products as numpy
+    coords = np.linspace(-2500, 2500, n)
+    ph = np.exp(1j * oracle.phase_array(coords, 33.0, -250.0, 12.5))
+    got = dev.phase_apply(dev.to_device(x), 1, ph).cpu().numpy()
+    assert _relerr(got, oracle.phase_values(x, coords, 1, 33.0, -250.0, 12.5)) < 1e-15
+
+
+def test_apodize_phase_complex64(dev, oracle):
+    n = 2048
+    x = _rand((3, n), "complex64", seed=9)
+    t = np.arange(n) * 2e-4
+    w = oracle.exp_window(t, 5.0)
+    got = dev.apodize(dev.to_device(x), 1, w).cpu().numpy()
+    assert _relerr(got, x.astype(np.complex128) * w) < 2e-7
+    coords = np.linspace(-2500, 2500, n)
+    ref = oracle.phase_values(x.astype(np.complex128), coords, 1, 33.0, -250.0, 12.5)
+    ph = np.exp(1j * oracle.phase_array(coords, 33.0, -250.0, 12.5))
+    assert _relerr(dev.phase_apply(dev.to_device(x), 1, ph).cpu().numpy(), ref) < 3e-7
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_roll_bit_exact(dev, dtype):
+    for n in (7, 8, 1000):
+        x = _rand((5, n), dtype, seed=n)
+        xd = dev.to_device(x)
+        np.testing.assert_array_equal(dev.roll(xd, 1, n // 2).cpu().numpy(), np.roll(x, n // 2, axis=1))
+        np.testing.assert_array_equal(dev.roll(xd, 1, (n + 1) // 2).cpu().numpy(), np.roll(x, (n + 1) // 2, axis=1))
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_absmax_argmax_first_occurrence(dev, oracle, dtype):
+    x = _rand((33, 300), dtype, seed=21)
+    flat_ref, _ = oracle.global_argmax(x)
+    amax, flat = dev.absmax_argmax(dev.to_device(x))
+    assert flat == flat_ref
+    assert abs(amax - np.abs(x).max()) < 1e-5 * np.abs(x).max()
+    # exact ties: the FIRST maximum in C order wins (np.argmax semantics, phasing.py:229)
+    y = np.zeros((16, 64), dtype)
+    for pos in [(9, 3), (4, 60), (4, 17), (12, 0)]:
+        y[pos] = 3.0 + 4.0j
+    y[4, 17] = -5.0  # same magnitude, different phase
+    _, flat = dev.absmax_argmax(dev.to_device(y))
+    assert flat == int(np.argmax(np.abs(y))) == 4 * 64 + 17
+    # 3-D array, arg-max is independent of which axis is the FID axis
+    z = _rand((4, 5, 6), dtype, seed=2)
+    assert dev.absmax_argmax(dev.to_device(z))[1] == int(np.argmax(np.abs(z)))
+
+
+CASES = [
+    # (n_batch, n_in, n_out, pad_left)  -- README C1, C2-shaped, >=2x, <2x, symmetric, mixed, prime
+    (5, 1024, 2048, 0),
+    (16, 2048, 4096, 0),
+    (3, 4096, 8192, 0),
+    (6, 1000, 4096, 0),
+    (6, 3000, 4096, 0),
+    (4, 32, 128, 48),
+    (7, 1536, 1536, 0),
+    (5, 1200, 1536, 0),
+    (3, 1531, 1531, 0),
+    (3, 700, 1531, 415),
+    (9, 100, 128, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("nb,n_in,n_out,pad_left", CASES)
+def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_left, dtype):
+    import torch
+
+    x = _rand((nb, n_in), dtype, seed=n_in + n_out)
+    x128 = x.astype(np.complex128)
+    pads = [(0, 0), (pad_left, n_out - n_in - pad_left)]
+    t = (np.arange(n_out) - pad_left) * 2e-4
+    w = oracle.exp_window(t, 5.0)
+    spec = oracle.to_spectrum_values(np.pad(x128, pads) * w, 1)
+    freq = np.roll(np.fft.fftfreq(n_out, d=2e-4), n_out // 2)
+    ph = np.exp(1j * oracle.phase_array(freq, 41.0, -333.0, float(freq[n_out // 3])))
+    ref = spec * ph
+    xd = dev.to_device(x)
+    rd = torch.float32 if dtype == "complex64" else torch.float64
+    wd = torch.from_numpy(w).to("cuda", rd)
+    phd = torch.from_numpy(ph).to("cuda", xd.dtype)
+    tol = TIGHT[dtype] * (4 if n_out == 1531 else 1)
+    # (1) arg-max pre-pass only
+    pre = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True)
+    amax, flat = dev.argmax_reduce(pre.absmax2, pre.argidx, n_out)
+    assert flat == int(np.argmax(np.abs(spec)))
+    assert abs(amax - np.abs(spec).max()) < 1e-5 * np.abs(spec).max()
+    np.testing.assert_array_equal(pre.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
+    # (2) unphased spectrum + arg-max in one launch
+    both = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_argmax=True)
+    assert _relerr(both.out.cpu().numpy(), spec) < tol
+    np.testing.assert_array_equal(both.argidx.cpu().numpy(), pre.argidx.cpu().numpy())
+    # (3) main pass: phased spectrum
+    main = dev.pipeline_fused(xd, n_out, pad_left, window=wd, phase_table=phd)
+    assert _relerr(main.out.cpu().numpy(), ref) < tol
+    assert _relerr(main.out.cpu().numpy(), ref) < TOL[dtype]
+    # (4) the fused result equals the staged device ops composed (zero_fill -> apodize -> fft+shift -> phase)
+    staged = dev.phase_apply(dev.fft(dev.apodize(dev.zero_fill(xd, 1, n_out, pad_left), 1, w), 1, shift_out=True),
+                             1, ph)
+    assert _relerr(main.out.cpu().numpy(), staged.cpu().numpy().astype(np.complex128)) < 4 * tol
+
+
+def test_unsupported_length_raises(dev):
+    from xmris_amd import _lib
+
+    x = dev.to_device(_rand((2, 9001), "complex64"))
+    with pytest.raises(_lib.UnsupportedLengthError):
+        dev.fft(x, 1)
+    with pytest.raises(RuntimeError):
+        dev.fft(x.cpu(), 1)  # no CPU path

@@ -1,0 +1,104 @@
+"""Host side of ``autophase``: the O(1)-per-dataset search for (p0, p1) on the ONE 1-D slice
+that holds the global |X| maximum (reference ``processing/phasing.py:100-157, 257-287``).
+
+The reference drives ``scipy.optimize.differential_evolution`` (best1bin, tol=0.01, seed=42)
+with objectives that go through ``phase()`` -> xarray on every evaluation.  Here the same
+optimiser is driven with the same arithmetic on plain ndarrays (no xarray object per
+evaluation).  The data-parallel parts of autophase -- the global arg-max and the broadcast
+phase multiply over the whole dataset -- run on the GPU (``xm_pipeline_fused``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+METHODS = ("acme", "peak_minima", "positivity")
+
+
+def phase_angles(coords: np.ndarray, p0: float, p1: float, pivot: float):
+    """phasing.py:56-69: phi = rad(p0) + rad(p1) * (c - pivot) / (max c - min c); scalar if range 0."""
+    x_min = float(coords.min())
+    x_max = float(coords.max())
+    x_range = x_max - x_min
+    p0_rad = np.radians(p0)
+    p1_rad = np.radians(p1)
+    if x_range == 0:
+        return p0_rad
+    return p0_rad + p1_rad * ((coords - pivot) / x_range)
+
+
+def phase_table(coords: np.ndarray, p0: float, p1: float, pivot: float) -> np.ndarray:
+    """e^{i phi} over the axis in fp64 (phasing.py:73); always an array of len(coords)."""
+    ph = phase_angles(np.asarray(coords, dtype=np.float64), p0, p1, pivot)
+    f = np.exp(1.0j * ph)
+    if np.ndim(f) == 0:
+        f = np.full(len(coords), f, dtype=np.complex128)
+    return f
+
+
+def _phased_real(ph, sl, coords, pivot):
+    p0 = ph[0]
+    p1 = ph[1] if len(ph) > 1 else 0.0
+    return np.real(sl * np.exp(1.0j * phase_angles(coords, p0, p1, pivot)))
+
+
+def acme_score(ph, sl, coords, pivot):
+    """phasing.py:100-122 -- entropy of the first derivative + negativity penalty."""
+    data = _phased_real(ph, sl, coords, pivot)
+    ds1 = np.abs((data[1:] - data[:-1]) / 2)
+    p1_prob = ds1 / np.sum(ds1)
+    p1_prob[p1_prob == 0] = 1
+    h1s = np.sum(-p1_prob * np.log(p1_prob))
+    as_ = data - np.abs(data)
+    pfun = 0.0
+    if np.sum(as_) < 0:
+        pfun = np.sum((as_ / 2) ** 2)
+    return (h1s + 1000 * pfun) / data.shape[-1] / np.max(data)
+
+
+def peak_minima_score(ph, sl, coords, pivot, target_idx, index_width):
+    """phasing.py:125-139."""
+    data = _phased_real(ph, sl, coords, pivot)
+    start = max(0, target_idx - index_width)
+    end = min(len(data), target_idx + index_width)
+    mina = np.min(data[start:target_idx]) if start < target_idx else data[target_idx]
+    minb = np.min(data[target_idx:end]) if end > target_idx else data[target_idx]
+    return np.abs(mina - minb)
+
+
+def roi_positivity_score(ph, sl, coords, pivot, target_idx, index_width):
+    """phasing.py:142-157."""
+    data = _phased_real(ph, sl, coords, pivot)
+    start = max(0, target_idx - index_width)
+    end = min(len(data), target_idx + index_width)
+    roi = data[start:end]
+    return np.sum(np.abs(roi[roi < 0])) * 5.0 - np.sum(roi[roi > 0])
+
+
+def index_width_of(coords: np.ndarray, peak_width: float) -> int:
+    """phasing.py:245-247."""
+    step = np.abs(coords[1] - coords[0])
+    return max(1, int(round((peak_width / 2.0) / step)))
+
+
+def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, index_width: int,
+          method: str = "acme", p0_only: bool = False, disp: bool = False):
+    """phasing.py:257-287.  Returns (p0, p1, scipy OptimizeResult)."""
+    import scipy.optimize
+
+    sl = np.asarray(sl, dtype=np.complex128)
+    coords = np.asarray(coords, dtype=np.float64)
+    if method == "acme":
+        fn, args = acme_score, (sl, coords, pivot)
+    elif method == "peak_minima":
+        fn, args = peak_minima_score, (sl, coords, pivot, target_idx, index_width)
+    elif method == "positivity":
+        fn, args = roi_positivity_score, (sl, coords, pivot, target_idx, index_width)
+    else:
+        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
+    opt = scipy.optimize.differential_evolution(
+        fn, bounds=bounds, args=args, strategy="best1bin", tol=0.01, seed=42, disp=disp
+    )
+    p0 = float(opt.x[0])
+    p1 = float(opt.x[1]) if not p0_only else 0.0
+    return p0, p1, opt

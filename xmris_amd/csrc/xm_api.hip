@@ -1,0 +1,307 @@
+// Host side of libxmris_hip.so: table cache, element-wise kernel launches and the extern "C" ABI
+// declared in include/xmris_hip.h.  gfx950 only.  The fused FFT kernels are instantiated per
+// storage precision in xm_launch_f32.hip / xm_launch_f64.hip.
+#include "xm_host.h"
+#include "xm_kernels.h"
+#include "xm_plans.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#define XM_VERSION_NUM 100  // 0.1.0
+
+static thread_local std::string g_err;
+int xm_fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+static int fail(int code, const std::string& msg) { return xm_fail(code, msg); }
+
+// ------------------------------------------------------------------------------------------------
+// Plan predicates
+// ------------------------------------------------------------------------------------------------
+bool xm_has_pow2_plan(int n, int dtype) {
+  (void)dtype;
+  switch (n) {
+#define XM_CASE(N, NT, ...) case N:
+    XM_PLANS_POW2(XM_CASE)
+    return true;
+    default:
+      return false;
+  }
+}
+
+bool xm_has_direct_plan(int n, int dtype) {
+  switch (n) {
+    XM_PLANS_POW2(XM_CASE)
+    XM_PLANS_OTHER(XM_CASE)
+    return true;
+    XM_PLANS_C64_ONLY(XM_CASE)
+    return dtype == XM_C64;
+#undef XM_CASE
+    default:
+      return false;
+  }
+}
+
+int xm_bluestein_m(int n) {  // smallest power of two >= max(2n-1, 16)
+  int m = 16;
+  while (m < 2 * n - 1) m <<= 1;
+  return m;
+}
+
+bool xm_supported(int n, int dtype) {
+  if (n < 2) return false;
+  if (xm_has_direct_plan(n, dtype)) return true;
+  const int m = xm_bluestein_m(n);
+  return xm_has_pow2_plan(m, dtype) || (m == 16384 && dtype == XM_C64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table cache (per kind, length, dtype, device), mutex-guarded
+// ------------------------------------------------------------------------------------------------
+struct TableKey {
+  int kind, n, m, dtype, device;
+  bool operator<(const TableKey& o) const {
+    return std::tie(kind, n, m, dtype, device) < std::tie(o.kind, o.n, o.m, o.dtype, o.device);
+  }
+};
+static std::mutex g_mu;
+static std::map<TableKey, void*> g_tables;
+
+void xm_unit(long long num, long long den, double sign, double& c, double& s) {
+  num %= den;
+  if (num < 0) num += den;
+  // octant symmetry on the integer fraction keeps the argument of cos/sin in [0, pi/4]
+  const long long q = (8 * num) / den;  // octant 0..7
+  long long r_num = num;
+  double cc, ss;
+  switch (q) {
+    case 0: { const double a = 2.0 * M_PI * (double)r_num / (double)den; cc = std::cos(a); ss = std::sin(a); break; }
+    case 1: { const double a = 2.0 * M_PI * (double)(den - 4 * num) / (double)(4 * den); cc = std::sin(a); ss = std::cos(a); break; }
+    case 2: { const double a = 2.0 * M_PI * (double)(4 * num - den) / (double)(4 * den); cc = -std::sin(a); ss = std::cos(a); break; }
+    case 3: { const double a = 2.0 * M_PI * (double)(den - 2 * num) / (double)(2 * den); cc = -std::cos(a); ss = std::sin(a); break; }
+    case 4: { const double a = 2.0 * M_PI * (double)(2 * num - den) / (double)(2 * den); cc = -std::cos(a); ss = -std::sin(a); break; }
+    case 5: { const double a = 2.0 * M_PI * (double)(3 * den - 4 * num) / (double)(4 * den); cc = -std::sin(a); ss = -std::cos(a); break; }
+    case 6: { const double a = 2.0 * M_PI * (double)(4 * num - 3 * den) / (double)(4 * den); cc = std::sin(a); ss = -std::cos(a); break; }
+    default: { const double a = 2.0 * M_PI * (double)(den - num) / (double)den; cc = std::cos(a); ss = -std::sin(a); break; }
+  }
+  c = cc;
+  s = sign * ss;
+}
+
+template <class T>
+static int upload(const std::vector<double>& re, const std::vector<double>& im, void** dev) {
+  const size_t n = re.size();
+  std::vector<Cx<T>> h(n);
+  for (size_t i = 0; i < n; ++i) {
+    h[i].re = (T)re[i];
+    h[i].im = (T)im[i];
+  }
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, (n ? n : 1) * sizeof(Cx<T>)));
+  if (n) HIP_TRY(hipMemcpy(d, h.data(), n * sizeof(Cx<T>), hipMemcpyHostToDevice));
+  *dev = d;
+  return XM_OK;
+}
+
+int xm_table_get(int kind, int n, int m, int dtype, xm_table_gen gen, const void* ctx, const void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  TableKey key{kind, n, m, dtype, dev};
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_tables.find(key);
+  if (it == g_tables.end()) {
+    std::vector<double> re, im;
+    gen(n, m, ctx, re, im);
+    void* d = nullptr;
+    int rc = dtype == XM_C64 ? upload<float>(re, im, &d) : upload<double>(re, im, &d);
+    if (rc) return rc;
+    it = g_tables.emplace(key, d).first;
+  }
+  *out = it->second;
+  return XM_OK;
+}
+
+static int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256LL * 16;  // 256 CUs x 16 workgroups, grid-stride the rest
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int check_common(const void* in, int64_t n_batch, int n, int dtype) {
+  if (!in && n_batch > 0) return fail(XM_ERR_INVALID_ARG, "null input pointer");
+  if (n_batch < 0 || n < 1) return fail(XM_ERR_INVALID_ARG, "negative batch or non-positive length");
+  if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "dtype must be XM_C64 or XM_C128");
+  return XM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extern "C"
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int xm_version(void) { return XM_VERSION_NUM; }
+
+const char* xm_last_error_string(void) { return g_err.c_str(); }
+
+int xm_clear_cache(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_tables) (void)hipFree(kv.second);
+  g_tables.clear();
+  return XM_OK;
+}
+
+int xm_fft_supported(int n, int dtype) { return xm_supported(n, dtype) ? 1 : 0; }
+
+int xm_plan_prepare(int n, int dtype) {
+  // run the pipeline on an empty batch: builds and caches every table the length needs
+  if (!xm_supported(n, dtype)) return fail(XM_ERR_UNSUPPORTED_N, "unsupported length " + std::to_string(n));
+  // tables are created lazily inside launch_plan even for n_batch == 0
+  if (dtype == XM_C64)
+    return xm_pipeline_f32(nullptr, n, nullptr, nullptr, nullptr, 0, n, n, 0, 0, nullptr, nullptr, nullptr);
+  return xm_pipeline_f64(nullptr, n, nullptr, nullptr, nullptr, 0, n, n, 0, 0, nullptr, nullptr, nullptr);
+}
+
+int xm_zero_fill(const void* in, void* out, int64_t n_batch, int n_in, int n_out, int pad_left, int dtype,
+                 void* stream) {
+  int rc = check_common(in, n_batch, n_in, dtype);
+  if (rc) return rc;
+  if (!out || n_out < n_in || pad_left < 0 || pad_left + n_in > n_out)
+    return fail(XM_ERR_INVALID_ARG, "zero_fill: bad output pointer or geometry");
+  if (n_batch == 0) return XM_OK;
+  const long long total = (long long)n_batch * n_out;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_zero_fill<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
+                       (Cx<float>*)out, (long long)n_batch, n_in, n_out, pad_left);
+  else
+    hipLaunchKernelGGL(k_zero_fill<double>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<double>*)in,
+                       (Cx<double>*)out, (long long)n_batch, n_in, n_out, pad_left);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, int n, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n, dtype);
+  if (rc) return rc;
+  if (!out || !window) return fail(XM_ERR_INVALID_ARG, "apodize: null output or window");
+  if (n_batch == 0) return XM_OK;
+  const long long total = (long long)n_batch * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_apodize<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
+                       (Cx<float>*)out, (const float*)window, (long long)n_batch, n);
+  else
+    hipLaunchKernelGGL(k_apodize<double>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<double>*)in,
+                       (Cx<double>*)out, (const double*)window, (long long)n_batch, n);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_phase_apply(const void* in, void* out, const void* phase_table, int64_t n_batch, int n, int dtype,
+                   void* stream) {
+  int rc = check_common(in, n_batch, n, dtype);
+  if (rc) return rc;
+  if (!out || !phase_table) return fail(XM_ERR_INVALID_ARG, "phase_apply: null output or table");
+  if (n_batch == 0) return XM_OK;
+  const long long total = (long long)n_batch * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_phase<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
+                       (Cx<float>*)out, (const Cx<float>*)phase_table, (long long)n_batch, n);
+  else
+    hipLaunchKernelGGL(k_phase<double>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<double>*)in,
+                       (Cx<double>*)out, (const Cx<double>*)phase_table, (long long)n_batch, n);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_roll(const void* in, void* out, int64_t n_batch, int n, int shift, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n, dtype);
+  if (rc) return rc;
+  if (!out || in == out) return fail(XM_ERR_INVALID_ARG, "roll: output must be a distinct buffer");
+  if (n_batch == 0) return XM_OK;
+  shift %= n;
+  if (shift < 0) shift += n;
+  const long long total = (long long)n_batch * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_roll<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
+                       (Cx<float>*)out, (long long)n_batch, n, shift);
+  else
+    hipLaunchKernelGGL(k_roll<double>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<double>*)in,
+                       (Cx<double>*)out, (long long)n_batch, n, shift);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_t* argidx, int dtype,
+                   void* stream) {
+  int rc = check_common(in, n_batch, n, dtype);
+  if (rc) return rc;
+  if (!absmax2 || !argidx) return fail(XM_ERR_INVALID_ARG, "absmax_rows: null outputs");
+  if (n_batch == 0) return XM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)(n_batch < 65536 * 4 ? n_batch : 65536 * 4);
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_absmax_rows<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in,
+                       (long long)n_batch, n, (float*)absmax2, argidx);
+  else
+    hipLaunchKernelGGL(k_absmax_rows<double>, dim3(grid), dim3(256), 0, st, (const Cx<double>*)in,
+                       (long long)n_batch, n, (double*)absmax2, argidx);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch, int n, void* out_max2,
+                     int64_t* out_flat, int dtype, void* stream) {
+  if (!absmax2 || !argidx || !out_max2 || !out_flat || n_batch < 1 || n < 1)
+    return fail(XM_ERR_INVALID_ARG, "argmax_reduce: null pointer or empty batch");
+  if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_argmax_final<float>, dim3(1), dim3(1024), 0, st, (const float*)absmax2, argidx,
+                       (long long)n_batch, n, (float*)out_max2, (long long*)out_flat);
+  else
+    hipLaunchKernelGGL(k_argmax_final<double>, dim3(1), dim3(1024), 0, st, (const double*)absmax2, argidx,
+                       (long long)n_batch, n, (double*)out_max2, (long long*)out_flat);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const void* window,
+                      const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                      void* absmax2, int32_t* argidx, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n_out, dtype);
+  if (rc) return rc;
+  if (n_in < 1 || pad_left < 0 || pad_left + n_in > n_out || in_row_stride < n_in)
+    return fail(XM_ERR_INVALID_ARG, "pipeline: bad zero-fill geometry or row stride");
+  if ((absmax2 == nullptr) != (argidx == nullptr))
+    return fail(XM_ERR_INVALID_ARG, "pipeline: absmax2 and argidx must be given together");
+  if (!out && !absmax2) return fail(XM_ERR_INVALID_ARG, "pipeline: nothing to produce");
+  if (out == in) return fail(XM_ERR_INVALID_ARG, "pipeline: in-place operation is not supported");
+  if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT))
+    return fail(XM_ERR_INVALID_ARG, "pipeline: unknown flag bits");
+  if (!xm_supported(n_out, dtype))
+    return fail(XM_ERR_UNSUPPORTED_N, "no in-LDS plan for length " + std::to_string(n_out));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XM_C64)
+    return xm_pipeline_f32(in, in_row_stride, out, window, phase_table, n_batch, n_in, n_out, pad_left, flags,
+                           absmax2, argidx, st);
+  return xm_pipeline_f64(in, in_row_stride, out, window, phase_table, n_batch, n_in, n_out, pad_left, flags,
+                         absmax2, argidx, st);
+}
+
+int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype, void* stream) {
+  if (!out) return fail(XM_ERR_INVALID_ARG, "fft: null output");
+  return xm_pipeline_fused(in, n, out, nullptr, nullptr, n_batch, n, n, 0, flags, nullptr, nullptr, dtype, stream);
+}
+
+}  // extern "C"

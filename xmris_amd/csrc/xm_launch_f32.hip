@@ -1,0 +1,10 @@
+// complex64 (2 x float32) instantiations of the fused kernels.
+#define XM_REAL float
+#include "xm_launch.inc"
+
+int xm_pipeline_f32(const void* in, int64_t in_stride, void* out, const void* window, const void* phase,
+                    int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags, void* absmax2,
+                    int32_t* argidx, hipStream_t st) {
+  return pipeline_typed(in, in_stride, out, window, phase, n_batch, n_in, n_out, pad_left, flags, absmax2, argidx,
+                        st);
+}

@@ -1,0 +1,48 @@
+// The in-LDS FFT plans.  X(N, NT, radices...): N points held by NT threads (NT a power of two,
+// P = N/NT points per thread absorbs the odd factors); every radix divides P and they multiply to N.
+#pragma once
+#include "xm_blockfft.h"
+
+// power-of-two lengths (also used as the half-length of the >=2x zero-fill path and as the
+// convolution length of the Bluestein path)
+#define XM_PLANS_POW2(X)      \
+  X(16, 1, 16)                \
+  X(32, 4, 8, 4)              \
+  X(64, 8, 8, 8)              \
+  X(128, 8, 16, 8)            \
+  X(256, 16, 16, 16)          \
+  X(512, 64, 8, 8, 8)         \
+  X(1024, 64, 16, 16, 4)      \
+  X(2048, 128, 16, 16, 8)     \
+  X(4096, 256, 16, 16, 16)    \
+  X(8192, 512, 16, 16, 16, 2)
+
+// tiny lengths and 3*2^k / 5*2^k lengths: generic kernel only
+#define XM_PLANS_OTHER(X)     \
+  X(2, 1, 2)                  \
+  X(4, 1, 4)                  \
+  X(8, 1, 8)                  \
+  X(384, 16, 24, 4, 4)        \
+  X(768, 32, 24, 8, 4)        \
+  X(1536, 64, 24, 8, 8)       \
+  X(3072, 64, 48, 8, 8)       \
+  X(6144, 128, 48, 16, 8)     \
+  X(640, 32, 20, 4, 4, 2)     \
+  X(1280, 32, 40, 8, 4)       \
+  X(2560, 64, 40, 8, 8)       \
+  X(5120, 128, 40, 8, 8, 2)
+
+// complex64 only: 16384 x 16 B does not fit the 160 KiB LDS
+#define XM_PLANS_C64_ONLY(X) X(16384, 1024, 16, 16, 16, 4)
+
+template <int N>
+struct PlanOf;
+#define XM_DEF_PLAN(N, NT, ...)               \
+  template <>                                 \
+  struct PlanOf<N> {                          \
+    using type = FftPlan<N, NT, __VA_ARGS__>; \
+  };
+XM_PLANS_POW2(XM_DEF_PLAN)
+XM_PLANS_OTHER(XM_DEF_PLAN)
+XM_PLANS_C64_ONLY(XM_DEF_PLAN)
+#undef XM_DEF_PLAN

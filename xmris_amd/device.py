@@ -1,0 +1,250 @@
+"""Array-level device operations of the xmris spectral hot path (MI355X / gfx950).
+
+Thin host wrappers around the C ABI of ``libxmris_hip.so``.  Inputs are complex torch tensors
+resident in HBM (``complex64`` or ``complex128``); PyTorch is used only for device memory and
+streams.  Each function names the reference statement it replaces.  There is no CPU fallback:
+a tensor that is not on a GPU raises.
+
+The FID / frequency axis may be any axis: it is moved last (one transposing copy) so that the
+kernels see ``[n_batch, n]`` C-contiguous rows, and moved back afterwards, exactly like
+``da.get_axis_num(dim)`` + ``axes=(axis,)`` in ``processing/fourier.py:152-153``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _dtype_code(x) -> int:
+    torch = _torch()
+    if x.dtype == torch.complex64:
+        return _lib.XM_C64
+    if x.dtype == torch.complex128:
+        return _lib.XM_C128
+    raise TypeError(f"xmris_amd kernels need complex64/complex128 data, got {x.dtype}")
+
+
+def _real_dtype(x):
+    torch = _torch()
+    return torch.float32 if x.dtype == torch.complex64 else torch.float64
+
+
+def _require_device(x):
+    torch = _torch()
+    if not isinstance(x, torch.Tensor):
+        raise TypeError("expected a torch.Tensor resident on the GPU")
+    if not x.is_cuda:
+        raise RuntimeError(
+            "xmris_amd has no CPU path: the tensor must live on a HIP device (use xmris_amd.to_device)"
+        )
+
+
+def _stream(x):
+    torch = _torch()
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def to_device(a, device="cuda", dtype=None):
+    """Host ndarray (or tensor) -> complex tensor in HBM; real input is promoted to complex."""
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        a = np.asarray(a)
+        if not np.iscomplexobj(a):
+            a = a.astype(np.complex128 if a.dtype != np.float32 else np.complex64)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    if not t.is_complex():
+        t = t.to(torch.complex128 if t.dtype == torch.float64 else torch.complex64)
+    return t.to(device)
+
+
+def _rows(x, axis):
+    """Move `axis` last and flatten the rest -> ([n_batch, n] contiguous, restore(y, n_new))."""
+    nd = x.dim()
+    axis = axis % nd
+    xm = x.movedim(axis, -1) if axis != nd - 1 else x
+    lead = tuple(xm.shape[:-1])
+    n = xm.shape[-1]
+    x2 = xm.reshape(-1, n)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+
+    def restore(y2):
+        y = y2.reshape(lead + (y2.shape[-1],))
+        if axis != nd - 1:
+            y = y.movedim(-1, axis).contiguous()
+        return y
+
+    return x2, restore
+
+
+def _table(values, like, complex_table: bool):
+    """fp64 host table -> device tensor of the storage precision (rounded once)."""
+    torch = _torch()
+    if isinstance(values, torch.Tensor):
+        t = values
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(values)))
+    want = like.dtype if complex_table else _real_dtype(like)
+    return t.to(device=like.device, dtype=want).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+def zero_fill(x, axis: int, target_points: int, pad_left: int = 0):
+    """fid.py:251 ``da.pad({dim: (pad_left, pad_right)}, constant_values=0)`` -- bit-exact copy."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n_in = x2.shape
+    out = torch.empty((nb, target_points), dtype=x.dtype, device=x.device)
+    _lib.call("xm_zero_fill", x2.data_ptr(), out.data_ptr(), nb, n_in, target_points, pad_left,
+              _dtype_code(x), _stream(x))
+    return restore(out)
+
+
+def apodize(x, axis: int, window):
+    """fid.py:139 ``da * weight`` with a real window over `axis` (host-computed in fp64)."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    w = _table(window, x, complex_table=False)
+    if w.numel() != n:
+        raise ValueError(f"window has {w.numel()} points, axis has {n}")
+    out = torch.empty_like(x2)
+    _lib.call("xm_apodize", x2.data_ptr(), out.data_ptr(), w.data_ptr(), nb, n, _dtype_code(x), _stream(x))
+    return restore(out)
+
+
+def phase_apply(x, axis: int, table):
+    """phasing.py:73 ``da * np.exp(1j * phase_array)`` with a complex table over `axis`."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    ph = _table(table, x, complex_table=True)
+    if ph.numel() != n:
+        raise ValueError(f"phase table has {ph.numel()} points, axis has {n}")
+    out = torch.empty_like(x2)
+    _lib.call("xm_phase_apply", x2.data_ptr(), out.data_ptr(), ph.data_ptr(), nb, n, _dtype_code(x),
+              _stream(x))
+    return restore(out)
+
+
+def roll(x, axis: int, shift: int):
+    """fourier.py:31-32 / 57-58 ``da.roll({dim: shift})`` on the data -- bit-exact."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    out = torch.empty_like(x2)
+    _lib.call("xm_roll", x2.data_ptr(), out.data_ptr(), nb, n, int(shift) % n, _dtype_code(x), _stream(x))
+    return restore(out)
+
+
+def fft(x, axis: int, inverse: bool = False, ortho: bool = True, shift_in: bool = False,
+        shift_out: bool = False):
+    """fourier.py:153 / 210 ``np.fft.(i)fftn(values, axes=(axis,), norm="ortho")`` with the
+    surrounding (i)fftshift rolls optionally folded into the same launch."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    if n == 1:  # length-1 transform is the identity for every norm used on this path
+        return restore(x2.clone())
+    flags = ((_lib.XM_FFT_INVERSE if inverse else 0) | (_lib.XM_FFT_ORTHO if ortho else 0)
+             | (_lib.XM_FFT_SHIFT_IN if shift_in else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0))
+    out = torch.empty_like(x2)
+    _lib.call("xm_fft1d_batched", x2.data_ptr(), out.data_ptr(), nb, n, flags, _dtype_code(x), _stream(x))
+    return restore(out)
+
+
+def absmax_argmax(x):
+    """phasing.py:229 ``int(np.argmax(np.abs(values)))``: (max |x|, first flat C-order index).
+
+    The flat arg-max does not depend on which axis is the FID axis, so the array is viewed as
+    [prod(shape[:-1]), shape[-1]] rows in its own layout.
+    """
+    _require_device(x)
+    torch = _torch()
+    xc = x if x.is_contiguous() else x.contiguous()
+    n = xc.shape[-1] if xc.dim() else 1
+    x2 = xc.reshape(-1, n)
+    nb = x2.shape[0]
+    rd = _real_dtype(x)
+    amax = torch.empty(nb, dtype=rd, device=x.device)
+    aidx = torch.empty(nb, dtype=torch.int32, device=x.device)
+    gmax = torch.empty(1, dtype=rd, device=x.device)
+    gflat = torch.empty(1, dtype=torch.int64, device=x.device)
+    code, st = _dtype_code(x), _stream(x)
+    _lib.call("xm_absmax_rows", x2.data_ptr(), nb, n, amax.data_ptr(), aidx.data_ptr(), code, st)
+    _lib.call("xm_argmax_reduce", amax.data_ptr(), aidx.data_ptr(), nb, n, gmax.data_ptr(), gflat.data_ptr(),
+              code, st)
+    return float(gmax.item()) ** 0.5, int(gflat.item())
+
+
+class FusedResult:
+    """Outputs of one fused launch: `out` ([n_batch, n_out] or None) and the arg-max pairs."""
+
+    __slots__ = ("out", "absmax2", "argidx")
+
+    def __init__(self, out, absmax2, argidx):
+        self.out, self.absmax2, self.argidx = out, absmax2, argidx
+
+
+def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
+                   ortho: bool = True, want_out: bool = True, want_argmax: bool = False, out=None,
+                   absmax2=None, argidx=None):
+    """One launch of zero-fill + window + FFT(+fftshift) [+ |X|^2 arg-max] [+ phase] on
+    ``x2`` = [n_batch, n_in] contiguous rows (FID axis last).  `window` / `phase_table` are
+    device tensors of the storage precision (real n_out / complex n_out) or None."""
+    _require_device(x2)
+    torch = _torch()
+    if x2.dim() != 2 or not x2.is_contiguous():
+        raise ValueError("pipeline_fused expects a contiguous [n_batch, n_in] tensor")
+    nb, n_in = x2.shape
+    rd = _real_dtype(x2)
+    if want_out and out is None:
+        out = torch.empty((nb, n_out), dtype=x2.dtype, device=x2.device)
+    if want_argmax:
+        if absmax2 is None:
+            absmax2 = torch.empty(nb, dtype=rd, device=x2.device)
+        if argidx is None:
+            argidx = torch.empty(nb, dtype=torch.int32, device=x2.device)
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    _lib.call(
+        "xm_pipeline_fused", x2.data_ptr(), n_in, out.data_ptr() if want_out else None,
+        window.data_ptr() if window is not None else None,
+        phase_table.data_ptr() if phase_table is not None else None, nb, n_in, n_out, pad_left, flags,
+        absmax2.data_ptr() if want_argmax else None, argidx.data_ptr() if want_argmax else None,
+        _dtype_code(x2), _stream(x2))
+    return FusedResult(out if want_out else None, absmax2 if want_argmax else None,
+                       argidx if want_argmax else None)
+
+
+def argmax_reduce(absmax2, argidx, n: int):
+    """Global (max |X|, flat index) from the per-spectrum pairs of a fused launch."""
+    torch = _torch()
+    nb = absmax2.numel()
+    gmax = torch.empty(1, dtype=absmax2.dtype, device=absmax2.device)
+    gflat = torch.empty(1, dtype=torch.int64, device=absmax2.device)
+    code = _lib.XM_C64 if absmax2.dtype == torch.float32 else _lib.XM_C128
+    _lib.call("xm_argmax_reduce", absmax2.data_ptr(), argidx.data_ptr(), nb, n, gmax.data_ptr(),
+              gflat.data_ptr(), code, torch.cuda.current_stream(absmax2.device).cuda_stream)
+    return float(gmax.item()) ** 0.5, int(gflat.item())
+
+
+def fft_supported(n: int, complex128: bool = False) -> bool:
+    if n == 1:
+        return True
+    return bool(_lib.load().xm_fft_supported(int(n), _lib.XM_C128 if complex128 else _lib.XM_C64))
