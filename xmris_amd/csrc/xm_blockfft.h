@@ -15,8 +15,13 @@
 #pragma once
 #include "xm_dft.h"
 
-template <int... Rs>
-struct RadixList {};
+// LDS rows are padded by one element every 128 bytes: 16 x 8 B (c64), 8 x 16 B (c128 or a two-lane
+// c64 pair), 4 x 32 B (two-lane c128).
+constexpr int xm_pad_shift(int elem_bytes) { return elem_bytes <= 8 ? 4 : (elem_bytes == 16 ? 3 : 2); }
+template <int SH>
+XM_DEV int xm_pad(int i) {
+  return i + (i >> SH);
+}
 
 template <int N_, int NT_, int... Rs>
 struct FftPlan {
@@ -49,56 +54,137 @@ struct FftPlan {
     return p == N;
   }
   static_assert(valid(), "radices must multiply to N and each divide P");
-  static constexpr int lds_elems() { return K > 1 ? (N + (N >> 4)) : 0; }
+  // exchange-buffer elements for an element of `es` bytes (one pad element per 128 bytes)
+  static constexpr int lds_elems(int es) { return K > 1 ? (N + (N >> xm_pad_shift(es))) : 0; }
+  // all radices (and NT) powers of two: index sums below are bitwise ORs, so the padded LDS address of
+  // (lane part + compile-time part) splits into a per-lane base plus an immediate offset
+  static constexpr bool pow2() {
+    for (int j = 0; j < K; ++j)
+      if (radix(j) & (radix(j) - 1)) return false;
+    return (NT & (NT - 1)) == 0;
+  }
 };
 
-XM_DEV int xm_pad(int i) { return i + (i >> 4); }
 
-template <class T, class PL>
-struct BlockFFT {
-  static constexpr int N = PL::N, NT = PL::NT, P = PL::P, K = PL::K;
+// Twiddle sources.  get<S, U, R_IDX>(k): twiddle of stage S, butterfly u, input r (1-based), table
+// column k = (b mod Ns).  All template arguments are compile-time so register tables stay in VGPRs.
+// Twiddles are scalar complex (Cx<S>) even when the data is two-lane (Cx<V>, S = ScalarOf<V>).
+template <class S, class PL>
+struct GlobalTw {  // every stage from the (L2-resident) global table
+  const Cx<S>* __restrict__ tw;
+  template <int ST, int U, int R1>
+  XM_DEV Cx<S> get(int k) const {
+    return tw[PL::tw_offset(ST) + (R1 - 1) * PL::ns(ST) + k];
+  }
+};
 
-  template <int S>
-  XM_DEV static void stage(Cx<T> (&v)[P], Cx<T>* lds, const Cx<T>* __restrict__ tw, int t) {
-    constexpr int R = PL::radix(S);
-    constexpr int Ns = PL::ns(S);
-    constexpr int PR = P / R;
-    constexpr bool last = (S == K - 1);
-    const Cx<T>* __restrict__ tws = tw + PL::tw_offset(S);
+template <class S, class PL>
+struct HotTw {  // middle stages from an LDS copy of the table, last stage from per-thread registers
+  static constexpr int K = PL::K;
+  static constexpr int RL = PL::radix(K - 1);
+  static constexpr int NREG = (K > 1) ? (PL::P / RL) * (RL - 1) : 1;
+  static constexpr int mid_size() { return K > 1 ? PL::tw_offset(K - 1) : 0; }
+  const Cx<S>* mid;  // LDS, mid_size() entries
+  Cx<S> reg[NREG];
+  // thread t loads its last-stage twiddles: butterfly b = t + NT*u, input r -> table[(r-1)*Ns + b]
+  XM_DEV void load(const Cx<S>* __restrict__ tw, int t) {
+    if constexpr (K > 1) {
+      constexpr int Ns = PL::ns(K - 1);
 #pragma unroll
-    for (int u = 0; u < PR; ++u) {
-      Cx<T> a[R];
+      for (int u = 0; u < PL::P / RL; ++u)
 #pragma unroll
-      for (int r = 0; r < R; ++r) a[r] = v[u + PR * r];
-      const int b = t + NT * u;
-      if constexpr (S > 0) {
-        constexpr bool full = (Ns * R == N);  // last stage: b < Ns always
-        const int k = full ? b : (b % Ns);
-#pragma unroll
-        for (int r = 1; r < R; ++r) a[r] = a[r] * tws[(r - 1) * Ns + k];
-      }
-      Dft<T, R>::run(a);
-      if constexpr (last) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[u + PR * r] = a[r];
-      } else {
-        const int o = (b / Ns) * (Ns * R) + (b % Ns);
-#pragma unroll
-        for (int r = 0; r < R; ++r) lds[xm_pad(o + r * Ns)] = a[r];
-      }
+        for (int r = 1; r < RL; ++r)
+          reg[u * (RL - 1) + (r - 1)] = tw[PL::tw_offset(K - 1) + (r - 1) * Ns + t + PL::NT * u];
     }
-    if constexpr (!last) {
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < P; ++q) v[q] = lds[xm_pad(t + NT * q)];
-      __syncthreads();
-      stage<S + 1>(v, lds, tw, t);
+  }
+  template <int ST, int U, int R1>
+  XM_DEV Cx<S> get(int k) const {
+    if constexpr (ST == K - 1)
+      return reg[U * (RL - 1) + (R1 - 1)];
+    else
+      return mid[PL::tw_offset(ST) + (R1 - 1) * PL::ns(ST) + k];
+  }
+};
+
+// V = element real type: a scalar (one spectrum per NT threads) or a two-lane vector (two transforms
+// carried side by side in the packed-math lanes).
+template <class V, class PL>
+struct BlockFFT {
+  using S = typename ScalarOf<V>::type;
+  static constexpr int N = PL::N, NT = PL::NT, P = PL::P, K = PL::K;
+  static constexpr int SH = xm_pad_shift((int)sizeof(Cx<V>));
+  static constexpr int lds_elems() { return PL::lds_elems((int)sizeof(Cx<V>)); }
+
+  template <int ST, int U, int R1, int R, class TW>
+  XM_DEV static void twiddle_row(Cx<V>* a, const TW& tw, int k) {
+    if constexpr (R1 < R) {
+      a[R1] = a[R1] * tw.template get<ST, U, R1>(k);
+      twiddle_row<ST, U, R1 + 1, R>(a, tw, k);
     }
   }
 
-  // forward, unnormalised.  `lds` = this spectrum's padded exchange buffer (PL::lds_elems()).
+  template <int ST, int U, class TW>
+  XM_DEV static void butterflies(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
+    constexpr int R = PL::radix(ST);
+    constexpr int Ns = PL::ns(ST);
+    constexpr int PR = P / R;
+    constexpr bool last = (ST == K - 1);
+    if constexpr (U < PR) {
+      Cx<V> a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = v[U + PR * r];
+      const int b = t + NT * U;
+      if constexpr (ST > 0) {
+        constexpr bool full = (Ns * R == N);  // last stage: b < Ns always
+        const int k = full ? b : (b % Ns);
+        twiddle_row<ST, U, 1, R>(a, tw, k);
+      }
+      Dft<V, R>::run(a);
+      if constexpr (last) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[U + PR * r] = a[r];
+      } else {
+        const int o = (b / Ns) * (Ns * R) + (b % Ns);
+        if constexpr (PL::pow2()) {  // o has zero bits where r*Ns lives: pad(o + c) = pad(o) + pad(c)
+          Cx<V>* wp = lds + xm_pad<SH>(o);
+#pragma unroll
+          for (int r = 0; r < R; ++r) wp[r * Ns + ((r * Ns) >> SH)] = a[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lds[xm_pad<SH>(o + r * Ns)] = a[r];
+        }
+      }
+      butterflies<ST, U + 1>(v, lds, tw, t);
+    }
+  }
+
+  template <int ST, class TW>
+  XM_DEV static void stage(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
+    constexpr bool last = (ST == K - 1);
+    butterflies<ST, 0>(v, lds, tw, t);
+    if constexpr (!last) {
+      __syncthreads();
+      if constexpr (PL::pow2()) {
+        const Cx<V>* rp = lds + xm_pad<SH>(t);
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = rp[NT * q + ((NT * q) >> SH)];
+      } else {
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = lds[xm_pad<SH>(t + NT * q)];
+      }
+      __syncthreads();
+      stage<ST + 1>(v, lds, tw, t);
+    }
+  }
+
+  // forward, unnormalised.  `lds` = this spectrum's padded exchange buffer (lds_elems()).
   // All threads of the workgroup must call it (it contains workgroup barriers).
-  XM_DEV static void run(Cx<T> (&v)[P], Cx<T>* lds, const Cx<T>* __restrict__ tw, int t) {
+  template <class TW>
+  XM_DEV static void run(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
     stage<0>(v, lds, tw, t);
+  }
+  XM_DEV static void run(Cx<V> (&v)[P], Cx<V>* lds, const Cx<S>* __restrict__ tw, int t) {
+    GlobalTw<S, PL> g{tw};
+    stage<0>(v, lds, g, t);
   }
 };

@@ -4,11 +4,42 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define XM_WAVE 64
 #define XM_DEV __device__ __forceinline__
 
-// Complex value in storage precision.  alignas(2*sizeof(T)) so that a c64 moves as one
-// dwordx2 and a c128 (or a pair of c64) as one dwordx4.
+// Two-lane vector of a real type.  Arithmetic on it maps to the packed-f32 VALU instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) on gfx950, which do two lanes for the issue cost of
+// one: the hot kernel carries (even-bin FFT, odd-bin FFT) in the two lanes.
+typedef float xm_f2 __attribute__((ext_vector_type(2)));
+typedef double xm_d2 __attribute__((ext_vector_type(2)));
+
+template <class T>
+struct ScalarOf {
+  using type = T;
+};
+template <>
+struct ScalarOf<xm_f2> {
+  using type = float;
+};
+template <>
+struct ScalarOf<xm_d2> {
+  using type = double;
+};
+template <class S>
+struct PairOf;
+template <>
+struct PairOf<float> {
+  using type = xm_f2;
+};
+template <>
+struct PairOf<double> {
+  using type = xm_d2;
+};
+
+// Complex value.  T is a real scalar (storage precision) or a two-lane vector of it.
+// alignas(2*sizeof(T)) so that a c64 moves as one dwordx2 and a c128 / pair of c64 as one dwordx4.
 template <class T>
 struct alignas(2 * sizeof(T)) Cx {
   T re, im;
@@ -36,6 +67,17 @@ XM_DEV Cx<T> operator*(Cx<T> a, Cx<T> b) {
 template <class T>
 XM_DEV Cx<T> operator*(Cx<T> a, T s) {
   return mk<T>(a.re * s, a.im * s);
+}
+// two-lane complex times a scalar complex / scalar real (the scalar is broadcast to both lanes)
+template <class V, class S, class = typename std::enable_if<!std::is_same<V, S>::value &&
+                                                            std::is_same<typename ScalarOf<V>::type, S>::value>::type>
+XM_DEV Cx<V> operator*(Cx<V> a, Cx<S> b) {
+  return mk<V>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+template <class V, class S, class = typename std::enable_if<!std::is_same<V, S>::value &&
+                                                            std::is_same<typename ScalarOf<V>::type, S>::value>::type>
+XM_DEV Cx<V> operator*(Cx<V> a, S s) {
+  return mk<V>(a.re * s, a.im * s);
 }
 template <class T>
 XM_DEV Cx<T> conj(Cx<T> a) {
@@ -96,6 +138,7 @@ constexpr double sin2pi(long k, long R) {
 // a * W_R^K  with  W_R = exp(-2*pi*i/R); trivial rotations cost no multiplies.
 template <int K_, int R, class T>
 XM_DEV Cx<T> mul_w(Cx<T> a) {
+  using S = typename ScalarOf<T>::type;
   constexpr int K = ((K_ % R) + R) % R;
   if constexpr (K == 0) {
     return a;
@@ -106,20 +149,20 @@ XM_DEV Cx<T> mul_w(Cx<T> a) {
   } else if constexpr (4 * K == 3 * R) {
     return mul_pi(a);
   } else if constexpr (8 * K == R) {  // (1 - i)/sqrt2
-    constexpr T c = T(0.70710678118654752440);
+    constexpr S c = S(0.70710678118654752440);
     return mk<T>((a.re + a.im) * c, (a.im - a.re) * c);
   } else if constexpr (8 * K == 3 * R) {  // (-1 - i)/sqrt2
-    constexpr T c = T(0.70710678118654752440);
+    constexpr S c = S(0.70710678118654752440);
     return mk<T>((a.im - a.re) * c, -(a.re + a.im) * c);
   } else if constexpr (8 * K == 5 * R) {  // (-1 + i)/sqrt2
-    constexpr T c = T(0.70710678118654752440);
+    constexpr S c = S(0.70710678118654752440);
     return mk<T>(-(a.re + a.im) * c, (a.re - a.im) * c);
   } else if constexpr (8 * K == 7 * R) {  // (1 + i)/sqrt2
-    constexpr T c = T(0.70710678118654752440);
+    constexpr S c = S(0.70710678118654752440);
     return mk<T>((a.re - a.im) * c, (a.re + a.im) * c);
   } else {
-    constexpr T c = T(xmct::cos2pi(K, R));
-    constexpr T s = T(-xmct::sin2pi(K, R));  // W = cos - i sin
+    constexpr S c = S(xmct::cos2pi(K, R));
+    constexpr S s = S(-xmct::sin2pi(K, R));  // W = cos - i sin
     return mk<T>(a.re * c - a.im * s, a.re * s + a.im * c);
   }
 }

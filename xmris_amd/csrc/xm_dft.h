@@ -24,8 +24,9 @@ struct Dft<T, 2> {
 template <class T>
 struct Dft<T, 3> {
   XM_DEV static void run(Cx<T>* a) {
-    constexpr T c = T(-0.5);
-    constexpr T s = T(0.86602540378443864676);  // sin(2pi/3)
+    using S = typename ScalarOf<T>::type;
+    constexpr S c = S(-0.5);
+    constexpr S s = S(0.86602540378443864676);  // sin(2pi/3)
     Cx<T> s12 = a[1] + a[2];
     Cx<T> d12 = a[1] - a[2];
     Cx<T> m = mk<T>(a[0].re + c * s12.re, a[0].im + c * s12.im);
@@ -51,10 +52,11 @@ struct Dft<T, 4> {
 template <class T>
 struct Dft<T, 5> {
   XM_DEV static void run(Cx<T>* a) {
-    constexpr T c1 = T(0.30901699437494742410);   // cos(2pi/5)
-    constexpr T c2 = T(-0.80901699437494742410);  // cos(4pi/5)
-    constexpr T s1 = T(0.95105651629515357212);   // sin(2pi/5)
-    constexpr T s2 = T(0.58778525229247312917);   // sin(4pi/5)
+    using S = typename ScalarOf<T>::type;
+    constexpr S c1 = S(0.30901699437494742410);   // cos(2pi/5)
+    constexpr S c2 = S(-0.80901699437494742410);  // cos(4pi/5)
+    constexpr S s1 = S(0.95105651629515357212);   // sin(2pi/5)
+    constexpr S s2 = S(0.58778525229247312917);   // sin(4pi/5)
     Cx<T> s14 = a[1] + a[4], d14 = a[1] - a[4];
     Cx<T> s23 = a[2] + a[3], d23 = a[2] - a[3];
     Cx<T> m1 = mk<T>(a[0].re + c1 * s14.re + c2 * s23.re, a[0].im + c1 * s14.im + c2 * s23.im);

@@ -9,6 +9,8 @@
 #pragma once
 #include "xm_blockfft.h"
 
+#include <type_traits>
+
 template <class T>
 struct PipeArgs {
   const Cx<T>* in;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(PL::NT* SPB) void k_pipe(PipeArgs<T> A) {
   const int ls = threadIdx.x / NT;
   const long long s = (long long)blockIdx.x * SPB + ls;
   const bool live = s < A.n_batch;
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem) + (size_t)ls * PL::lds_elems();
+  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem) + (size_t)ls * BlockFFT<T, PL>::lds_elems();
 
   Cx<T> v[P];
   const Cx<T>* __restrict__ row = A.in + (live ? s : 0) * A.in_stride;
@@ -142,78 +144,187 @@ struct alignas(4 * sizeof(T)) CxPair {
   Cx<T> a, b;
 };
 
-template <class T, class PL, int SPB>
-__global__ __launch_bounds__(PL::NT* SPB) void k_pipe_zf2(PipeArgs<T> A) {
-  constexpr int H = PL::N, N = 2 * PL::N, NT = PL::NT, P = PL::P;
-  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
-  const int t = threadIdx.x % NT;
-  const int ls = threadIdx.x / NT;
-  const long long s = (long long)blockIdx.x * SPB + ls;
-  const bool live = s < A.n_batch;
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem) + (size_t)ls * PL::lds_elems();
+// ---- raw buffer access: SGPR descriptor (base, size) + 32-bit lane offset + scalar offset.  Reads
+// beyond the descriptor's size return 0 and such writes are dropped, in hardware, so the zero fill
+// needs neither branches nor 64-bit per-lane address arithmetic.
+typedef unsigned xm_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned xm_u4 __attribute__((ext_vector_type(4)));
 
-  Cx<T> ve[P], vo[P];
-  const Cx<T>* __restrict__ row = A.in + (live ? s : 0) * A.in_stride;
+XM_DEV __amdgpu_buffer_rsrc_t xm_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+XM_DEV Cx<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, Cx<double>*) {
+  const xm_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  Cx<double> c;
+  __builtin_memcpy(&c, &u, 16);
+  return c;
+}
+XM_DEV CxPair<float> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<float>*) {
+  const xm_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  CxPair<float> c;
+  __builtin_memcpy(&c, &u, 16);
+  return c;
+}
+XM_DEV CxPair<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<double>*) {
+  CxPair<double> c;
+  c.a = buf_load(r, voff, soff, (Cx<double>*)nullptr);
+  c.b = buf_load(r, voff + 16u, soff, (Cx<double>*)nullptr);
+  return c;
+}
+XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<float> v) {
+  xm_u4 u;
+  __builtin_memcpy(&u, &v, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<double> v) {
+  xm_u4 u;
+  __builtin_memcpy(&u, &v.a, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+  __builtin_memcpy(&u, &v.b, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff + 16u, soff, 0);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N_, class F>
+XM_DEV void static_for(F&& f) {
+  if constexpr (I < N_) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N_>(f);
+  }
+}
+
+// Persistent kernel: gridDim.x workgroups of NT threads loop over the spectra (stride gridDim.x).
+//   * everything that does not depend on the spectrum is loaded ONCE per workgroup: the window
+//     samples w[j], the per-thread rotation W_N^t, the last-stage twiddles (registers) and the
+//     middle-stage twiddles (LDS copy) -- no table traffic inside the loop except the phase table;
+//   * the next spectrum's FID samples are prefetched into registers before the current FFTs start,
+//     so the HBM read of spectrum i+1 overlaps the butterflies / LDS exchanges of spectrum i;
+//   * W_N^{t + NT*q} = W_N^t * W_{2P}^q : one per-thread complex rotation plus compile-time
+//     constants, i.e. the odd-bin half is a half-sample-shifted copy of the even-bin butterfly;
+//   * output index of (E[m], O[m]), m = t + NT*q, after the fftshift roll: (2*NT*q + shift) mod N
+//     + 2t with shift a multiple of 2*NT -- a scalar base per q plus one per-lane offset, so all
+//     addressing is SGPR base + 32-bit lane offset, and each lane stores one 16-byte (c64) word.
+// MODE bits: 1 = write the spectrum, 2 = multiply by the phase table, 4 = per-spectrum arg-max.
+enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4 };
+
+// waves per SIMD the register allocator must leave room for: two resident workgroups per CU
+template <class T, class PL>
+constexpr int zf2_waves() {
+  int w = PL::NT / 128;  // 2 workgroups of NT threads over 4 SIMDs
+  if (sizeof(T) == 8) w /= 2;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
+template <class T, class PL, int MODE>
+__global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T> A) {
+  constexpr unsigned N = 2 * PL::N, NT = PL::NT;
+  constexpr int P = PL::P;
+  constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  using V = typename PairOf<T>::type;  // lane x: even-bin half-FFT, lane y: odd-bin half-FFT
+  using FFT = BlockFFT<V, PL>;
+  using HT = HotTw<T, PL>;
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
+  Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
+  T* red_v = reinterpret_cast<T*>(mid + HT::mid_size());  // own region: the loop reuses `lds` at once
+  int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
+  const unsigned t = threadIdx.x;
+
+  HT tw;
+  tw.mid = mid;
+  tw.load(A.tw, (int)t);
+  for (unsigned i = t; i < (unsigned)HT::mid_size(); i += NT) mid[i] = A.tw[i];
+  const Cx<T> rot = A.aux[t];  // W_N^t
+  const unsigned n_in = (unsigned)A.n_in;
+  const unsigned toff = t - (unsigned)A.pad_left;  // wraps for t < pad_left -> fails the range test
+  T w[P];  // window sample * FFT scale; 0 outside the acquired samples (the zero fill)
 #pragma unroll
   for (int q = 0; q < P; ++q) {
-    const int j = t + NT * q;  // < H
-    const int src = j - A.pad_left;
-    Cx<T> x = mk<T>(T(0), T(0));
-    if (live && src >= 0 && src < A.n_in) {
-      x = row[src];
-      if (A.window) x = x * A.window[j];
-    }
-    ve[q] = x;
-    vo[q] = x * A.aux[j];  // W_N^j
+    const bool ok = (toff + NT * q) < n_in;
+    w[q] = ok ? (A.window ? A.window[t + NT * q] * A.scale : A.scale) : T(0);
+  }
+  __syncthreads();
+
+  // FID sample j = t + NT*q of a row lives at row[j - pad_left].  Positions outside the acquired
+  // samples read a clamped (valid) address and are zeroed by their window weight w = 0, so the loads
+  // need no branches: uniform row pointer + 32-bit lane offset.  (ROCm 7.2's
+  // __builtin_amdgcn_raw_buffer_load_b64 lowers to a ONE-dword load, so the 8-byte FID loads do not
+  // use the buffer path; the 16-byte phase loads and spectrum stores below do.)
+  constexpr unsigned CB = sizeof(Cx<T>);
+  const unsigned last_in = n_in - 1u;
+  Cx<T> xr[P];
+  long long s = blockIdx.x;
+  if (s < A.n_batch) {
+    const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
+#pragma unroll
+    for (int q = 0; q < P; ++q) xr[q] = row[min(toff + NT * q, last_in)];
   }
 
-  BlockFFT<T, PL>::run(ve, lds, A.tw, t);
-  BlockFFT<T, PL>::run(vo, lds, A.tw, t);
-
-  T bv = T(-1);
-  int bi = 0x7fffffff;
-  Cx<T>* __restrict__ orow = A.out ? A.out + (live ? s : 0) * (long long)N : nullptr;
-  const bool paired = (A.out_shift & 1) == 0;
+  for (; s < A.n_batch; s += gridDim.x) {
+    // Opaque copies: every LDS / global address below is a cheap function of (t, shift, n_in).  Without
+    // this the compiler hoists all of them out of the persistent loop (they are loop-invariant) and
+    // pays for it with >100 live VGPRs/SGPRs; recomputing them per spectrum costs a few ALU ops.
+    unsigned tt = t, sh = (unsigned)A.out_shift, nin = n_in, pl = (unsigned)A.pad_left;
+    asm volatile("" : "+v"(tt));
+    asm volatile("" : "+s"(sh));
+    asm volatile("" : "+s"(nin));
+    asm volatile("" : "+s"(pl));
+    const unsigned toff2 = tt - pl;
+    Cx<V> v[P];
+    static_for<0, P>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const Cx<T> e = xr[q] * w[q];
+      const Cx<T> o = mul_w<q, 2 * P, T>(e * rot);
+      v[q].re = V{e.re, o.re};
+      v[q].im = V{e.im, o.im};
+    });
+    const long long s2 = s + gridDim.x;
+    if (s2 < A.n_batch) {  // prefetch the next FID while this one is transformed
+      const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
 #pragma unroll
-  for (int q = 0; q < P; ++q) {
-    const int m = t + NT * q;
-    int k0 = 2 * m + A.out_shift;
-    if (k0 >= N) k0 -= N;
-    int k1 = k0 + 1;
-    if (k1 >= N) k1 -= N;
-    Cx<T> xe = ve[q] * A.scale;
-    Cx<T> xo = vo[q] * A.scale;
-    if (A.absmax2) {
-      amax_take(bv, bi, xe.re * xe.re + xe.im * xe.im, k0);
-      amax_take(bv, bi, xo.re * xo.re + xo.im * xo.im, k1);
+      for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
     }
-    if (orow) {
-      if (paired) {  // k0 even, k1 = k0 + 1: one 16-byte (c64) word per thread, fully coalesced
-        if (A.phase) {
-          const CxPair<T> ph = *reinterpret_cast<const CxPair<T>*>(A.phase + k0);
+
+    FFT::run(v, lds, tw, (int)tt);
+
+    const unsigned t2 = 2u * tt;
+    if constexpr (AMAX) {  // thread-local max |X|^2 first (packed), then the first index holding it
+      T bv = T(-1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
+        bv = fmax(bv, fmax(m2.x, m2.y));
+      }
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2);
+        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
+        bi = min(bi, m2.x == bv ? k0 : 0x7fffffff);
+        bi = min(bi, m2.y == bv ? k0 + 1 : 0x7fffffff);
+      }
+      amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+    }
+    if constexpr (WRITE) {
+      const __amdgpu_buffer_rsrc_t rout = xm_rsrc(A.out + s * (long long)N, N * CB);
+      const __amdgpu_buffer_rsrc_t rph = xm_rsrc(A.phase, PHASE ? N * CB : 0u);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
+        Cx<T> xe = mk<T>(v[q].re.x, v[q].im.x);
+        Cx<T> xo = mk<T>(v[q].re.y, v[q].im.y);
+        if constexpr (PHASE) {
+          const CxPair<T> ph = buf_load(rph, t2 * CB, base * CB, (CxPair<T>*)nullptr);
           xe = xe * ph.a;
           xo = xo * ph.b;
         }
         CxPair<T> o;
         o.a = xe;
         o.b = xo;
-        if (live) *reinterpret_cast<CxPair<T>*>(orow + k0) = o;
-      } else {
-        if (A.phase) {
-          xe = xe * A.phase[k0];
-          xo = xo * A.phase[k1];
-        }
-        if (live) {
-          orow[k0] = xe;
-          orow[k1] = xo;
-        }
+        buf_store(rout, t2 * CB, base * CB, o);
       }
     }
-  }
-  if (A.absmax2) {
-    T* red_v = reinterpret_cast<T*>(xm_smem);
-    int* red_i = reinterpret_cast<int*>(red_v + (NT * SPB) / XM_WAVE + 1);
-    amax_reduce_store<T, NT>(bv, bi, t, live, s, A.absmax2, A.argidx, red_v, red_i);
   }
 }
 
@@ -231,7 +342,7 @@ __global__ __launch_bounds__(PL::NT* SPB) void k_bluestein(PipeArgs<T> A) {
   const long long s = (long long)blockIdx.x * SPB + ls;
   const bool live = s < A.n_batch;
   const int n = A.n;
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem) + (size_t)ls * PL::lds_elems();
+  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem) + (size_t)ls * BlockFFT<T, PL>::lds_elems();
 
   Cx<T> v[P];
   const Cx<T>* __restrict__ row = A.in + (live ? s : 0) * A.in_stride;

@@ -17,6 +17,16 @@
   X(4096, 256, 16, 16, 16)    \
   X(8192, 512, 16, 16, 16, 2)
 
+// half-length plans of the persistent ">= 2x zero-fill" kernel (k_zf2): 8 points per thread keep the
+// whole per-thread state (two half-FFTs, prefetched FID, window, last-stage twiddles) under 128 VGPRs,
+// i.e. 4 waves per SIMD
+#define XM_PLANS_ZF2(X)       \
+  X(512, 64, 8, 8, 8)         \
+  X(1024, 128, 8, 8, 4, 4)    \
+  X(2048, 256, 8, 8, 8, 4)    \
+  X(4096, 512, 8, 8, 8, 8)    \
+  X(8192, 1024, 8, 8, 8, 8, 2)
+
 // tiny lengths and 3*2^k / 5*2^k lengths: generic kernel only
 #define XM_PLANS_OTHER(X)     \
   X(2, 1, 2)                  \
@@ -45,4 +55,14 @@ struct PlanOf;
 XM_PLANS_POW2(XM_DEF_PLAN)
 XM_PLANS_OTHER(XM_DEF_PLAN)
 XM_PLANS_C64_ONLY(XM_DEF_PLAN)
+#undef XM_DEF_PLAN
+
+template <int N>
+struct Zf2PlanOf;
+#define XM_DEF_PLAN(N, NT, ...)               \
+  template <>                                 \
+  struct Zf2PlanOf<N> {                       \
+    using type = FftPlan<N, NT, __VA_ARGS__>; \
+  };
+XM_PLANS_ZF2(XM_DEF_PLAN)
 #undef XM_DEF_PLAN
