@@ -1,0 +1,146 @@
+"""Array-level fused hot path:  zero_fill -> apodize_exp -> to_spectrum -> autophase.
+
+This is what the four chained accessor calls of the reference's quick start
+(``README.md:66-73``) amount to on the data, done in two data-parallel launches instead of six
+full-size numpy passes:
+
+  pre-pass   read the FIDs, FFT in LDS, emit only (max |X|^2, arg-max) per spectrum
+  exchange   device reduce -> 16 bytes to the host (over ranks: caller-provided gather)
+  solve      the one arg-max spectrum (64 KiB D2H) -> differential evolution on the host
+  main pass  read the FIDs again, FFT, multiply by e^{i phi}, write the phased spectra
+
+All coordinate arithmetic stays on the host in fp64, restating ``processing/fid.py:254-263``
+(zero-fill coords), ``:136`` (window), ``processing/fourier.py:95-98, 31`` (frequency coords,
+roll) and ``processing/phasing.py:226-247, 56-73`` (selection, phase ramp).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import autophase_solver as aps
+from . import device as dev
+
+
+@dataclass
+class PipelinePlan:
+    """Host-side metadata of one pipeline configuration (depends on coords, not on the data)."""
+
+    n_in: int
+    n_out: int
+    pad_left: int
+    time: np.ndarray          # zero-fill-extrapolated time coordinate (fid.py:257-263)
+    freq: np.ndarray          # fftshifted frequency coordinate (fourier.py:98, 31-32)
+    window_host: np.ndarray   # exp(-pi*lb*t) in fp64 (fid.py:136) or ones
+    window: object = None     # device tensor, storage precision
+    extra: dict = field(default_factory=dict)
+
+
+def zero_fill_coords(t: np.ndarray, target_points: int, pad_left: int) -> np.ndarray:
+    """fid.py:257-263."""
+    delta = t[1] - t[0]
+    if pad_left == 0:
+        return t[0] + np.arange(target_points) * delta
+    return (t[0] - (pad_left * delta)) + np.arange(target_points) * delta
+
+
+def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end") -> PipelinePlan:
+    import torch
+
+    n_in = x2.shape[-1]
+    t = np.asarray(t, dtype=np.float64)
+    if target_points <= n_in:  # fid.py:235-236: no-op zero fill
+        n_out, pad_left, tt = n_in, 0, t
+    else:
+        n_out = int(target_points)
+        if position == "end":
+            pad_left = 0
+        elif position == "symmetric":
+            pad_left = (n_out - n_in) // 2
+        else:
+            raise ValueError("`position` must be either 'end' or 'symmetric'.")
+        tt = zero_fill_coords(t, n_out, pad_left) if len(t) > 1 else t
+    win = np.exp(-np.pi * lb * tt) if lb is not None else np.ones(n_out)
+    delta = (tt[1] - tt[0]) if len(tt) > 1 else 1.0
+    freq = np.roll(np.fft.fftfreq(n_out, d=delta), n_out // 2)
+    rd = torch.float32 if x2.dtype == torch.complex64 else torch.float64
+    wdev = torch.from_numpy(np.ascontiguousarray(win)).to(device=x2.device, dtype=rd)
+    return PipelinePlan(n_in, n_out, pad_left, tt, freq, win, wdev)
+
+
+@dataclass
+class AutophaseResult:
+    p0: float
+    p1: float
+    pivot: float
+    flat_index: int
+    target_idx: int
+    max_abs: float
+    nfev: int = 0
+    fun: float = float("nan")
+
+
+def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
+                     p0_only=False, exchange=None, rank_offset_rows=0, disp=False):
+    """phasing.py:226-287 on the outputs of the pre-pass.  `exchange(max_abs, flat)` may merge the
+    per-rank winners (returns (owner_is_me, global_flat)); default = single device."""
+    n = plan.n_out
+    amax, flat = dev.argmax_reduce(absmax2, argidx, n)
+    gflat = rank_offset_rows * n + flat
+    mine = True
+    if exchange is not None:
+        mine, gflat = exchange(amax, gflat)
+    k = gflat % n
+    if target_coord is not None:  # phasing.py:233-235
+        target_idx = int(np.argmin(np.abs(plan.freq - target_coord)))
+        pivot = float(target_coord)
+    else:  # phasing.py:237-238
+        target_idx = int(k)
+        pivot = float(plan.freq[k])
+    res = AutophaseResult(0.0, 0.0, pivot, int(gflat), target_idx, amax)
+    if mine:
+        # The optimiser is chaotic in its input (a 1e-7 perturbation of the slice can steer the search
+        # into another local minimum of the ACME landscape), so the ONE spectrum it works on is
+        # recomputed in complex128 from the stored samples, as the reference's float64 path would.
+        import torch
+
+        row = gflat // n - rank_offset_rows
+        x1 = x2[row:row + 1].to(torch.complex128)
+        w64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
+        sl = dev.pipeline_fused(x1, n, plan.pad_left, window=w64).out[0].cpu().numpy()
+        iw = aps.index_width_of(plan.freq, peak_width)
+        p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp)
+        res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
+    return res, mine
+
+
+def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=100, target_coord=None,
+        p0_only: bool = False, out=None, plan: PipelinePlan | None = None, params=None):
+    """Fused hot path on ``x2`` = [n_batch, n_time] complex rows resident in HBM.
+
+    Returns (phased [n_batch, n_out] tensor, AutophaseResult, plan).  `params=(p0, p1)` skips the
+    solver (used by parity tests that inject the oracle's parameters)."""
+    import torch
+
+    if plan is None:
+        plan = make_plan(x2, t, target_points, lb)
+    n = plan.n_out
+    pre = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True)
+    res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only) \
+        if params is None else (_selection_only(pre, plan, target_coord), True)
+    if params is not None:
+        res.p0, res.p1 = float(params[0]), float(params[1])
+    table = aps.phase_table(plan.freq, res.p0, res.p1, res.pivot)
+    ph = torch.from_numpy(table).to(device=x2.device, dtype=x2.dtype)
+    main = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, phase_table=ph, out=out)
+    return main.out, res, plan
+
+
+def _selection_only(pre, plan, target_coord):
+    amax, flat = dev.argmax_reduce(pre.absmax2, pre.argidx, plan.n_out)
+    k = flat % plan.n_out
+    if target_coord is not None:
+        return AutophaseResult(0.0, 0.0, float(target_coord), flat,
+                               int(np.argmin(np.abs(plan.freq - target_coord))), amax)
+    return AutophaseResult(0.0, 0.0, float(plan.freq[k]), flat, int(k), amax)
