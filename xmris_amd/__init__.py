@@ -8,3 +8,16 @@ reference's accessor method names.  Hand-written HIP kernels reached through a C
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+from .accessor import XmrisAccessor, register_xarray_accessor
+from .config import ATTRS, COORDS, DIMS
+from .fused import spectral_pipeline
+from .labeled import Coordinate, LabeledArray
+from .processing import (apodize_exp, apodize_lg, autophase, fft, fftc, fftshift, ifft, ifftc, ifftshift, phase,
+                         to_fid, to_spectrum, zero_fill)
+
+DataArray = LabeledArray  # convenience alias for code written against xarray's constructor signature
+register_xarray_accessor()  # no-op when xarray is absent or the name `xmr` is already owned
+
+__all__ = ["ATTRS", "COORDS", "DIMS", "Coordinate", "DataArray", "LabeledArray", "XmrisAccessor",
+           "apodize_exp", "apodize_lg", "autophase", "fft", "fftc", "fftshift", "ifft", "ifftc", "ifftshift",
+           "phase", "register_xarray_accessor", "spectral_pipeline", "to_fid", "to_spectrum", "zero_fill"]

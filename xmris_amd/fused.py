@@ -1,0 +1,80 @@
+"""Labelled front end of the fused hot path (``.xmr.spectral_pipeline``).
+
+Produces exactly the DataArray that ``da.xmr.zero_fill(target_points=T).xmr.apodize_exp(lb=L)
+.xmr.to_spectrum().xmr.autophase()`` produces (dims, coordinates with attrs, lineage attrs, name),
+but the data makes two passes through HBM instead of six (see ``xmris_amd.pipeline``).
+"""
+from __future__ import annotations
+
+import copy as _copy
+
+import numpy as np
+
+from . import pipeline as pl
+from .config import ATTRS, COORDS, DIMS
+from .labeled import Coordinate, LabeledArray, as_labeled, like_input
+from .processing._common import device_data
+from .utils import _check_dims, term_attrs
+
+
+def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,
+                      out_dim: str = DIMS.frequency, position: str = "end", method: str = "acme",
+                      peak_width=100, target_coord=None, p0_only: bool = False, mode: str = "single", **kwargs):
+    src = as_labeled(da)
+    _check_dims(src, dim, "zero_fill")
+    if position not in ("end", "symmetric"):
+        raise ValueError("`position` must be either 'end' or 'symmetric'.")
+    if mode == "all":
+        raise NotImplementedError(
+            "Applying autophase to each spectrum individually ('all') is not yet implemented."
+        )
+    elif mode != "single":
+        raise ValueError("Mode must be 'single' or 'all'.")
+    if method not in ("acme", "peak_minima", "positivity"):
+        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    t = src.coords[dim].values  # apodize_exp needs the coordinate (KeyError otherwise)
+    x, _ = device_data(src)
+    ax = src.get_axis_num(dim)
+    nd = x.dim()
+    xm = x.movedim(ax, -1) if ax != nd - 1 else x
+    lead = tuple(xm.shape[:-1])
+    x2 = xm.reshape(-1, xm.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    plan = pl.make_plan(x2, t, target_points, lb, position)
+    if ax != nd - 1:
+        # the global arg-max must follow the ORIGINAL C order (phasing.py:229); with the FID axis moved
+        # the fused pre-pass would break ties differently, so fall back to the staged calls
+        from .processing import apodize_exp, autophase, to_spectrum, zero_fill
+
+        out = autophase(to_spectrum(apodize_exp(zero_fill(src, dim, target_points, position), dim, lb), dim, out_dim),
+                        out_dim, method=method, peak_width=peak_width, target_coord=target_coord,
+                        p0_only=p0_only, **kwargs)
+        return like_input(out, da)
+    y2, res, plan = pl.run(x2, t, target_points, lb, method=method, peak_width=peak_width,
+                           target_coord=target_coord, p0_only=p0_only, plan=plan)
+    y = y2.reshape(lead + (plan.n_out,))
+
+    n, n_out = src.sizes[dim], plan.n_out
+    new_dims = tuple(out_dim if d == dim else d for d in src.dims)
+    coords = {}
+    for k, c in src.coords.items():
+        if c.dim != dim:
+            coords[k] = c
+        elif k != dim:  # bystander coordinate along the FID axis: NaN-padded, then rolled with the data
+            v = np.full(n_out, np.nan)
+            v[plan.pad_left:plan.pad_left + n] = c.values
+            coords[k] = Coordinate(out_dim, np.roll(v, n_out // 2), c.attrs)
+    term = COORDS.frequency if (dim == DIMS.time and out_dim in (None, DIMS.frequency)) else None
+    coords[out_dim] = Coordinate(out_dim, plan.freq, term_attrs(term) if term is not None else {})
+    attrs = _copy.copy(src.attrs)
+    if target_points > n:
+        attrs[ATTRS.zero_fill_target] = target_points
+        attrs[ATTRS.zero_fill_position] = position
+    attrs[ATTRS.apodization_lb] = lb
+    attrs[ATTRS.phase_p0] = res.p0
+    attrs[ATTRS.phase_p1] = res.p1
+    attrs[ATTRS.phase_pivot] = res.pivot
+    attrs[ATTRS.phase_pivot_coord] = out_dim
+    name = src.name if src.name == dim == out_dim else None
+    return like_input(LabeledArray(y, new_dims, coords, attrs, name), da)

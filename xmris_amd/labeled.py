@@ -1,0 +1,195 @@
+"""A small labelled-array container with the subset of the ``xarray.DataArray`` surface that the
+spectral hot path touches (dims, coords with attrs, attrs, name, ``.values``, ``.copy``,
+``get_axis_num``, ``isel``) and a ``.xmr`` accessor.
+
+Why it exists: (1) ``xarray`` is an optional dependency of this backend (it is absent from the
+build and GPU images), so the drop-in API must be usable and testable without it; (2) the data
+may stay resident in HBM between chained ``.xmr`` calls (``data`` is then a torch tensor on the
+GPU and ``.values`` copies to the host on demand), which a numpy-backed ``xarray.DataArray`` cannot
+express.  ``from_xarray`` / ``to_xarray`` convert losslessly when xarray is installed.
+"""
+from __future__ import annotations
+
+import copy as _copy
+
+import numpy as np
+
+
+class Coordinate:
+    """One coordinate variable: the dimension it runs along, its values (host, fp64 as given) and
+    attrs such as ``long_name`` / ``units``."""
+
+    __slots__ = ("dim", "values", "attrs")
+
+    def __init__(self, dim, values, attrs=None):
+        self.dim = str(dim)
+        self.values = np.asarray(values)
+        self.attrs = dict(attrs or {})
+
+    def copy(self):
+        return Coordinate(self.dim, self.values.copy(), dict(self.attrs))
+
+    def min(self):
+        return self.values.min()
+
+    def max(self):
+        return self.values.max()
+
+    def __len__(self):
+        return len(self.values)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def __repr__(self):
+        return f"Coordinate(dim={self.dim!r}, n={len(self.values)}, attrs={self.attrs})"
+
+
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda")
+
+
+class LabeledArray:
+    def __init__(self, data, dims, coords=None, attrs=None, name=None):
+        if not _is_tensor(data):
+            data = np.asarray(data)
+        self.data = data
+        self.dims = tuple(str(d) for d in dims)
+        if len(self.dims) != len(self.data.shape):
+            raise ValueError(f"{len(self.dims)} dims for data of shape {tuple(self.data.shape)}")
+        self.coords = {}
+        for k, c in (coords or {}).items():
+            if isinstance(c, Coordinate):
+                c = c.copy()
+            elif isinstance(c, tuple) and len(c) in (2, 3):  # (dim, values[, attrs]) like xarray
+                c = Coordinate(c[0], c[1], c[2] if len(c) == 3 else None)
+            else:
+                c = Coordinate(k, c)
+            if c.dim in self.dims and len(c.values) != self.data.shape[self.dims.index(c.dim)]:
+                raise ValueError(f"coordinate {k!r} has {len(c.values)} points, dim {c.dim!r} has "
+                                 f"{self.data.shape[self.dims.index(c.dim)]}")
+            self.coords[str(k)] = c
+        self.attrs = dict(attrs or {})
+        self.name = name
+
+    # ---- xarray-like surface ------------------------------------------------------------------
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def ndim(self):
+        return len(self.dims)
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def dtype(self):
+        if _is_tensor(self.data):
+            return np.dtype(str(self.data.dtype).replace("torch.", ""))
+        return self.data.dtype
+
+    @property
+    def is_device_resident(self) -> bool:
+        return _is_tensor(self.data)
+
+    @property
+    def values(self) -> np.ndarray:
+        """Host ndarray (copies device-resident data over PCIe)."""
+        if _is_tensor(self.data):
+            return self.data.detach().cpu().numpy()
+        return self.data
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def get_axis_num(self, dim) -> int:
+        return self.dims.index(dim)
+
+    def copy(self, deep=True, data=None):
+        if data is None:
+            data = self.data.clone() if _is_tensor(self.data) else self.data.copy()
+        return LabeledArray(data, self.dims, self.coords, _copy.copy(self.attrs), self.name)
+
+    def assign_attrs(self, *args, **kw):
+        out = self.copy(data=self.data)
+        for a in args:
+            out.attrs.update(a)
+        out.attrs.update(kw)
+        return out
+
+    def isel(self, indexers=None, **kw):
+        """Integer / slice selection along named dims (integers drop the dim, like xarray)."""
+        sel = dict(indexers or {}, **kw)
+        idx, dims = [], []
+        for d in self.dims:
+            i = sel.get(d, slice(None))
+            idx.append(i)
+            if isinstance(i, slice):
+                dims.append(d)
+        coords = {}
+        for k, c in self.coords.items():
+            if c.dim in sel:
+                i = sel[c.dim]
+                if isinstance(i, slice):
+                    coords[k] = Coordinate(c.dim, c.values[i], c.attrs)
+            else:
+                coords[k] = c
+        return LabeledArray(self.data[tuple(idx)], dims, coords, _copy.copy(self.attrs), self.name)
+
+    @property
+    def real(self):
+        return LabeledArray(self.values.real, self.dims, self.coords, _copy.copy(self.attrs), self.name)
+
+    @property
+    def imag(self):
+        return LabeledArray(self.values.imag, self.dims, self.coords, _copy.copy(self.attrs), self.name)
+
+    def to_host(self):
+        return self.copy(data=self.values.copy()) if _is_tensor(self.data) else self
+
+    @property
+    def xmr(self):
+        from .accessor import XmrisAccessor
+
+        return XmrisAccessor(self)
+
+    def __repr__(self):
+        where = "HBM" if _is_tensor(self.data) else "host"
+        return (f"<xmris_amd.LabeledArray {self.sizes} {self.dtype} [{where}] coords={list(self.coords)} "
+                f"attrs={list(self.attrs)}>")
+
+    # ---- xarray bridge ------------------------------------------------------------------------
+    @classmethod
+    def from_xarray(cls, da):
+        coords = {}
+        for k, c in da.coords.items():
+            if c.ndim == 1:
+                coords[str(k)] = Coordinate(c.dims[0], np.asarray(c.values), dict(c.attrs))
+        return cls(np.asarray(da.values), da.dims, coords, dict(da.attrs), da.name)
+
+    def to_xarray(self):
+        import xarray as xr
+
+        coords = {k: xr.Variable(c.dim, c.values, attrs=dict(c.attrs)) for k, c in self.coords.items()
+                  if c.dim in self.dims}
+        return xr.DataArray(self.values, dims=self.dims, coords=coords, attrs=dict(self.attrs), name=self.name)
+
+
+def is_xarray(obj) -> bool:
+    return type(obj).__module__.startswith("xarray")
+
+
+def as_labeled(obj) -> LabeledArray:
+    if isinstance(obj, LabeledArray):
+        return obj
+    if is_xarray(obj):
+        return LabeledArray.from_xarray(obj)
+    raise TypeError(f"expected an xarray.DataArray or xmris_amd.LabeledArray, got {type(obj).__name__}")
+
+
+def like_input(result: LabeledArray, original):
+    """Return the result in the caller's container type (xarray in -> xarray out, on the host)."""
+    return result.to_xarray() if is_xarray(original) else result

@@ -1,0 +1,44 @@
+"""Shared host helpers of the processing functions: device upload, dim bookkeeping."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import device as dev
+from ..labeled import Coordinate, LabeledArray, as_labeled, like_input  # noqa: F401
+
+
+def device_data(da: LabeledArray):
+    """The array's data as a complex tensor in HBM (uploads host data once; real data is promoted
+    to complex of the same precision) and whether the input was real-valued."""
+    was_real = not np.issubdtype(da.dtype, np.complexfloating)
+    if da.is_device_resident:
+        x = da.data
+        if was_real:
+            x = dev.to_device(x)
+        return x, was_real
+    return dev.to_device(da.data), was_real
+
+
+def maybe_real(x, was_real: bool):
+    """Ops that keep a real array real in the reference (pad, roll, real window) return the real part."""
+    if not was_real:
+        return x
+    r = x.real
+    return r.contiguous() if hasattr(r, "contiguous") else np.ascontiguousarray(r)
+
+
+def to_host(x) -> np.ndarray:
+    """Device tensor (or ndarray) -> host ndarray."""
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def binary_op_name(da: LabeledArray, dim: str):
+    """xarray keeps a binary op's name only when both operands share it; the other operand here is
+    the coordinate of `dim` (named `dim`)."""
+    return da.name if da.name == dim else None
+
+
+def replace_dim_coords(da: LabeledArray, dim: str, new_len: int):
+    """Coordinates of the result: those along other dims unchanged, those along `dim` dropped
+    (the caller re-creates the dimension coordinate)."""
+    return {k: c for k, c in da.coords.items() if c.dim != dim}

@@ -1,0 +1,107 @@
+"""Manual and automatic phase correction on the GPU.
+
+Host-side mirror of the reference's ``src/xmris/processing/phasing.py``: ``phase`` applies one
+(p0, p1, pivot) ramp to the whole N-D array (one broadcast-multiply launch); ``autophase``
+(mode="single") finds the global |X| maximum on the device, optimises (p0, p1) on that ONE 1-D
+slice on the host (same scipy differential evolution as the reference) and applies the result to
+everything.
+"""
+from __future__ import annotations
+
+import copy as _copy
+import warnings
+
+import numpy as np
+
+from .. import autophase_solver as aps
+from .. import device as dev
+from ..config import ATTRS, DIMS
+from ..utils import _check_dims
+from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
+                      to_host)
+
+
+def _global_argmax(src: LabeledArray, x):
+    """phasing.py:229-231 / 50-52: flat arg-max of |values| in C order, unravelled."""
+    _, flat = dev.absmax_argmax(x)
+    return flat, np.unravel_index(flat, src.shape)
+
+
+def _phase_labeled(src: LabeledArray, x, dim, p0, p1, pivot) -> LabeledArray:
+    coords = src.coords[dim].values
+    table = aps.phase_table(coords, p0, p1, pivot)  # fp64 on the host (phasing.py:56-73)
+    y = dev.phase_apply(x, src.get_axis_num(dim), table)
+    out = src.copy(data=y)
+    out.name = binary_op_name(src, dim)
+    out.attrs = _copy.copy(src.attrs)  # phasing.py:76
+    if pivot is not None and ATTRS.phase_pivot_coord in out.attrs:  # phasing.py:79-88
+        old = out.attrs[ATTRS.phase_pivot_coord]
+        if old != dim:
+            warnings.warn(
+                f"Applying phase in '{dim}', but previous phase operations "
+                f"were recorded in '{old}'. Ensure your pivot value "
+                f"({pivot}) matches the current dimension's units."
+            )
+    out.attrs[ATTRS.phase_p0] = p0  # phasing.py:91-94
+    out.attrs[ATTRS.phase_p1] = p1
+    out.attrs[ATTRS.phase_pivot] = pivot
+    out.attrs[ATTRS.phase_pivot_coord] = dim
+    return out
+
+
+def phase(da, dim: str = DIMS.frequency, p0: float = 0.0, p1: float = 0.0, pivot: float = None):
+    """Zero- and first-order phase correction, phi = rad(p0) + rad(p1)*(c - pivot)/(max c - min c)
+    (reference ``phasing.py:10-96``).  Default pivot: coordinate of the global |X| maximum."""
+    src = as_labeled(da)
+    _check_dims(src, dim, "phase")
+    x, _ = device_data(src)
+    if pivot is None:  # phasing.py:49-53
+        _, idx = _global_argmax(src, x)
+        pivot = float(src.coords[dim].values[idx[src.get_axis_num(dim)]])
+    return like_input(_phase_labeled(src, x, dim, p0, p1, pivot), da)
+
+
+def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "single",
+              peak_width: float = 0.5, target_coord: float | None = None, p0_only: bool = False,
+              lb: float = 0.0, temp_time_dim: str = DIMS.time, **kwargs):
+    """Automatic phase correction (reference ``phasing.py:161-290``)."""
+    src = as_labeled(da)
+    _check_dims(src, dim, "autophase")
+    kwargs.setdefault("disp", False)
+    if mode == "all":
+        raise NotImplementedError(
+            "Applying autophase to each spectrum individually ('all') is not yet implemented."
+        )
+    elif mode != "single":
+        raise ValueError("Mode must be 'single' or 'all'.")
+
+    coords = src.coords[dim].values
+    x, _ = device_data(src)
+    ax = src.get_axis_num(dim)
+    _, idx = _global_argmax(src, x)  # device reduction, 16 bytes to the host
+    if target_coord is not None:  # phasing.py:233-235
+        target_idx = int(np.argmin(np.abs(coords - target_coord)))
+        pivot = float(target_coord)
+    else:  # phasing.py:237-238
+        target_idx = int(idx[ax])
+        pivot = float(coords[target_idx])
+
+    # the ONE 1-D slice through the global maximum (phasing.py:241-242), upcast to complex128
+    sel = tuple(slice(None) if i == ax else int(j) for i, j in enumerate(idx))
+    sl = np.asarray(to_host(x[sel]), dtype=np.complex128)
+    index_width = aps.index_width_of(coords, peak_width)  # phasing.py:245-247
+
+    work, work_coords = sl, coords
+    if lb > 0:  # phasing.py:250-253, on the 1-D slice only (three tiny launches)
+        from .fid import apodize_exp, to_fid, to_spectrum
+
+        one = LabeledArray(sl, (dim,), {dim: Coordinate(dim, coords)})
+        tmp = to_spectrum(apodize_exp(to_fid(one, dim=dim, out_dim=temp_time_dim), dim=temp_time_dim, lb=lb),
+                          dim=temp_time_dim, out_dim=dim)
+        work, work_coords = tmp.values, tmp.coords[dim].values
+
+    if method not in aps.METHODS:
+        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    p0_opt, p1_opt, _ = aps.solve(work, work_coords, pivot, target_idx, index_width, method=method,
+                                  p0_only=p0_only, disp=kwargs.get("disp"))
+    return like_input(_phase_labeled(src, x, dim, p0_opt, p1_opt, pivot), da)  # phasing.py:290
