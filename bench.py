@@ -71,6 +71,7 @@ def main():
 
     from xmris_amd import autophase_solver as aps
     from xmris_amd import device as dev
+    from xmris_amd import pipeline, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,7 +97,6 @@ def main():
 
     # host metadata exactly as the accessor layer computes it (fid.py:257-263, 136; fourier.py:95-98, 31)
     tt = t[0] + np.arange(N) * (t[1] - t[0])
-    window = torch.from_numpy(np.exp(-np.pi * args.lb * tt)).to(device=device, dtype=rdtype)
     freq = np.roll(np.fft.fftfreq(N, d=tt[1] - tt[0]), N // 2)
 
     out = torch.empty((nv, N), dtype=cdtype, device=device)
@@ -106,47 +106,41 @@ def main():
     times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": []}
     last = {}
 
+    plan = pipeline.make_plan(x, t, N, args.lb)
+    assert np.array_equal(plan.freq, freq)
+    ddev = device if dist is not None else "cpu"
+
     def step(record):
         ev[0].record()
-        dev.pipeline_fused(x, N, 0, window=window, want_out=False, want_argmax=True, absmax2=absmax2, argidx=argidx)
+        dev.pipeline_fused(x, N, 0, window=plan.window, want_out=False, want_argmax=True, absmax2=absmax2,
+                           argidx=argidx)
         ev[1].record()
         t0 = time.perf_counter()
-        amax, flat = dev.argmax_reduce(absmax2, argidx, N)  # syncs: 16 B D2H
-        gflat = rank * nv * N + flat
-        owner = rank
-        if dist is not None:  # O(1) exchange: (max, global flat index) per rank
-            mine = torch.tensor([amax, float(gflat)], dtype=torch.float64, device=device)
-            allv = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)
-            pairs = [(float(a[0]), int(a[1])) for a in allv]
-            best = max(pairs, key=lambda p: (p[0], -p[1]))
-            owner = pairs.index(best)
-            gflat = best[1]
-        k = gflat % N
-        pivot = float(freq[k])
-        sol = torch.empty(2, dtype=torch.float64, device=device)
-        t1 = time.perf_counter()
-        if owner == rank:
-            row = (gflat // N) - rank * nv
-            sl = dev.pipeline_fused(x[row:row + 1], N, 0, window=window).out[0].cpu().numpy()
-            p0, p1, opt = aps.solve(sl, freq, pivot, k, aps.index_width_of(freq, 100))
-            last["nfev"] = int(opt.nfev)
-            sol[0], sol[1] = p0, p1
-        if dist is not None:
-            dist.broadcast(sol, src=owner)
-        p0, p1 = (float(v) for v in sol.cpu())
+        state = {}
+
+        def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
+            state["t_x0"] = time.perf_counter()
+            owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev)
+            state["owner"] = owner
+            state["t_x1"] = time.perf_counter()
+            return owner == rank, gwin
+
+        res, mine = pipeline.select_and_solve(x, plan, absmax2, argidx, exchange=exchange, rank_offset_rows=rank * nv)
+        p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev)
         t2 = time.perf_counter()
-        ph = torch.from_numpy(aps.phase_table(freq, p0, p1, pivot)).to(device=device, dtype=cdtype)
+        ph = torch.from_numpy(aps.phase_table(plan.freq, p0, p1, res.pivot)).to(device=device, dtype=cdtype)
         ev[2].record()
-        dev.pipeline_fused(x, N, 0, window=window, phase_table=ph, out=out)
+        dev.pipeline_fused(x, N, 0, window=plan.window, phase_table=ph, out=out)
         ev[3].record()
-        last.update(p0=p0, p1=p1, pivot=pivot, flat=gflat, owner=owner)
+        last.update(p0=p0, p1=p1, pivot=res.pivot, flat=res.flat_index, owner=state["owner"])
+        if mine:
+            last["nfev"] = res.nfev
         if record:
             torch.cuda.synchronize()
             times["pre_ms"].append(ev[0].elapsed_time(ev[1]))
             times["main_ms"].append(ev[2].elapsed_time(ev[3]))
-            times["exchange_ms"].append((t1 - t0) * 1e3)
-            times["solve_ms"].append((t2 - t1) * 1e3)
+            times["exchange_ms"].append((state["t_x1"] - t0) * 1e3)
+            times["solve_ms"].append((t2 - state["t_x1"]) * 1e3)
 
     def barrier():
         if dist is not None:
@@ -193,14 +187,14 @@ def main():
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_pipe_zf2 (main pass: zero-fill+window+FFT+fftshift+phase)",
+            "bound": "hbm", "kernel": "k_zf2<float, FftPlan<4096,512,8,8,8,8>, 3> (main pass: zero-fill+window+FFT+fftshift+phase)",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
         },
         "breakdown_ms": {
             "prepass_kernel": pre_ms, "main_kernel": main_ms,
-            "argmax_exchange": float(np.mean(times["exchange_ms"])),
-            "slice_and_de_solve": float(np.mean(times["solve_ms"])),
+            "argmax_reduce_and_exchange": float(np.mean(times["exchange_ms"])),
+            "slice_de_solve_broadcast": float(np.mean(times["solve_ms"])),
             "streaming_spectra_per_s_per_gpu": nv / (stream_ms * 1e-3),
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
