@@ -100,6 +100,23 @@ int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const vo
                       const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left,
                       unsigned flags, void* absmax2, int32_t* argidx, int dtype, void* stream);
 
+/* ---- A7  host-side autophase search (no GPU involved; O(1) per dataset) ------------------------
+ * Objectives of processing/phasing.py:100-157 and the differential-evolution driver the reference
+ * reaches through scipy (phasing.py:276-284: best1bin, tol, seed, bounds p0 in [-180,180] deg,
+ * p1 in [-4000,4000] deg).  `slice_re_im`: n interleaved complex128 samples of the ONE spectrum through the
+ * global maximum; `coords`: its n float64 coordinates; method 0 = acme, 1 = peak_minima, 2 = positivity. */
+void* xm_solver_create(const double* slice_re_im, const double* coords, int n, double pivot, int method,
+                       int target_idx, int index_width);
+void xm_solver_destroy(void* solver);
+/* objective value at x = (p0[, p1]) in degrees */
+double xm_solver_score(void* solver, const double* x, int nx);
+long xm_solver_nfev(void* solver);
+/* OpenMP team size of one objective evaluation (<= 0: min(16, cores); 1 = serial); returns the value set */
+int xm_solver_set_threads(void* solver, int threads);
+/* the differential-evolution generations (no polish); returns 0 = converged, 1 = maxiter reached */
+int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxiter, double* x_out /*[2]*/,
+                 double* fun_out, int* nfev_out, int* nit_out);
+
 #ifdef __cplusplus
 }
 #endif

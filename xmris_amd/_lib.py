@@ -46,6 +46,12 @@ SIGNATURES = {
     "xm_absmax_rows": (_i, [_p, _l, _i, _p, _p, _i, _p]),
     "xm_argmax_reduce": (_i, [_p, _p, _l, _i, _p, _p, _i, _p]),
     "xm_pipeline_fused": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
+    "xm_solver_create": (_p, [_p, _p, _i, ctypes.c_double, _i, _i, _i]),
+    "xm_solver_destroy": (None, [_p]),
+    "xm_solver_score": (ctypes.c_double, [_p, _p, _i]),
+    "xm_solver_nfev": (ctypes.c_long, [_p]),
+    "xm_solver_set_threads": (_i, [_p, _i]),
+    "xm_solver_de": (_i, [_p, _i, _u, ctypes.c_double, _i, _p, _p, _p, _p]),
 }
 
 

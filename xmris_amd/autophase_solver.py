@@ -80,13 +80,80 @@ def index_width_of(coords: np.ndarray, peak_width: float) -> int:
     return max(1, int(round((peak_width / 2.0) / step)))
 
 
+class NativeObjective:
+    """The three objectives evaluated by libxmris_hip.so's host solver (vectorised C++, fp64)."""
+
+    def __init__(self, sl, coords, pivot, target_idx, index_width, method):
+        from . import _lib
+
+        self._lib = _lib.load()
+        self._sl = np.ascontiguousarray(sl, dtype=np.complex128)
+        self._c = np.ascontiguousarray(coords, dtype=np.float64)
+        self._h = self._lib.xm_solver_create(self._sl.ctypes.data, self._c.ctypes.data, len(self._sl), float(pivot),
+                                             METHODS.index(method), int(target_idx), int(index_width))
+        if not self._h:
+            raise ValueError("xm_solver_create rejected the slice (needs n >= 2 and a valid target index)")
+
+    def __call__(self, x):
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        return self._lib.xm_solver_score(self._h, xx.ctypes.data, len(xx))
+
+    def set_threads(self, n):
+        return self._lib.xm_solver_set_threads(self._h, int(n))
+
+    def de(self, p0_only, seed=42, tol=0.01, maxiter=1000):
+        import ctypes
+
+        x = (ctypes.c_double * 2)()
+        fun, nfev, nit = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+        rc = self._lib.xm_solver_de(self._h, int(bool(p0_only)), seed, tol, maxiter, x, ctypes.byref(fun),
+                                    ctypes.byref(nfev), ctypes.byref(nit))
+        return rc, np.array(x[:1 if p0_only else 2]), fun.value, nfev.value, nit.value
+
+    def __del__(self):
+        try:
+            self._lib.xm_solver_destroy(self._h)
+        except Exception:
+            pass
+
+
+def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
+    """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
+    run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective
+    values, objectives vectorised over host cores), the final L-BFGS-B polish is scipy's, exactly as
+    `DifferentialEvolutionSolver.solve` does it."""
+    import scipy.optimize
+
+    obj = NativeObjective(sl, coords, pivot, target_idx, index_width, method)
+    obj.set_threads(0)  # back-to-back evaluations: an OpenMP team pays off
+    rc, x, fun, nfev, nit = obj.de(p0_only)
+    obj.set_threads(1)  # isolated calls from Python: serial is faster than waking a sleeping team
+    bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
+    res = scipy.optimize.minimize(obj, np.copy(x), method="L-BFGS-B", bounds=bounds)
+    nfev += res.nfev
+    lo = np.array([b[0] for b in bounds])
+    hi = np.array([b[1] for b in bounds])
+    polished = bool(res.fun < fun and res.success and np.all(res.x <= hi) and np.all(lo <= res.x))
+    if polished:
+        x, fun = res.x, float(res.fun)
+    opt = scipy.optimize.OptimizeResult(x=x, fun=fun, nfev=nfev, nit=nit, success=(rc == 0), polished=polished)
+    return opt
+
+
 def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, index_width: int,
-          method: str = "acme", p0_only: bool = False, disp: bool = False):
-    """phasing.py:257-287.  Returns (p0, p1, scipy OptimizeResult)."""
+          method: str = "acme", p0_only: bool = False, disp: bool = False, engine: str = "native"):
+    """phasing.py:257-287.  Returns (p0, p1, OptimizeResult).  engine="native" (default) runs the
+    optimiser's generations in libxmris_hip.so; engine="scipy" calls scipy's driver with the numpy
+    objectives above (the reference's own route, ~15x slower; kept for cross-checks)."""
     import scipy.optimize
 
     sl = np.asarray(sl, dtype=np.complex128)
     coords = np.asarray(coords, dtype=np.float64)
+    if method not in METHODS:
+        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    if engine == "native" and len(sl) >= 2:
+        opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only)
+        return float(opt.x[0]), (float(opt.x[1]) if not p0_only else 0.0), opt
     if method == "acme":
         fn, args = acme_score, (sl, coords, pivot)
     elif method == "peak_minima":
