@@ -111,7 +111,8 @@ void xm_solver_destroy(void* solver);
 /* objective value at x = (p0[, p1]) in degrees */
 double xm_solver_score(void* solver, const double* x, int nx);
 long xm_solver_nfev(void* solver);
-/* OpenMP team size of one objective evaluation (<= 0: min(16, cores); 1 = serial); returns the value set */
+/* team size of one objective evaluation inside xm_solver_de (<= 0: min(12, hardware threads / 2); 1 = serial);
+ * returns the value set.  Outside xm_solver_de evaluations are always serial. */
 int xm_solver_set_threads(void* solver, int threads);
 /* the differential-evolution generations (no polish); returns 0 = converged, 1 = maxiter reached */
 int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxiter, double* x_out /*[2]*/,

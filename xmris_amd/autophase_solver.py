@@ -125,9 +125,8 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
     import scipy.optimize
 
     obj = NativeObjective(sl, coords, pivot, target_idx, index_width, method)
-    obj.set_threads(0)  # back-to-back evaluations: an OpenMP team pays off
-    rc, x, fun, nfev, nit = obj.de(p0_only)
-    obj.set_threads(1)  # isolated calls from Python: serial is faster than waking a sleeping team
+    rc, x, fun, nfev, nit = obj.de(p0_only)  # worker pool spins for the duration of the generations
+    # the polish's isolated evaluations below run serially (the pool is parked outside xm_solver_de)
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
     res = scipy.optimize.minimize(obj, np.copy(x), method="L-BFGS-B", bounds=bounds)
     nfev += res.nfev

@@ -102,6 +102,9 @@ double np_sum_small(const double* a, int n) {
 extern "C" {
 
 double xm_solver_score(void* h, const double* x, int nx);
+int xm_solver_get_threads(void* h);
+void xm_solver_pool_begin(int threads);
+void xm_solver_pool_end(void);
 
 // scipy 1.15.3 DifferentialEvolutionSolver.solve() without the polish, for
 // strategy="best1bin", popsize=15, mutation=(0.5, 1), recombination=0.7, init="latinhypercube",
@@ -109,7 +112,12 @@ double xm_solver_score(void* h, const double* x, int nx);
 // Returns 0 when converged, 1 when maxiter was reached.
 int xm_solver_de(void* h, int p0_only, unsigned seed, double tol, int maxiter, double* x_out, double* fun_out,
                  int* nfev_out, int* nit_out) {
-    const int N = p0_only ? 1 : 2;
+  const int N = p0_only ? 1 : 2;
+  // evaluations come back to back from here on: let the worker pool spin for the duration
+  struct PoolScope {
+    explicit PoolScope(int t) { xm_solver_pool_begin(t); }
+    ~PoolScope() { xm_solver_pool_end(); }
+  } scope(xm_solver_get_threads(h));
   const double lo[2] = {-180.0, -4000.0}, hi[2] = {180.0, 4000.0};
   double arg1[2], arg2[2];
   for (int j = 0; j < N; ++j) {
