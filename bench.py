@@ -8,7 +8,8 @@ synthetic batch that is already resident in HBM:
  -> the arg-max spectrum (one workgroup, 64 KiB D2H) -> host differential evolution (p0, p1)
  -> phase table (fp64 on the host, 64 KiB H2D)
  -> main kernel (fused zero-fill + window + FFT + fftshift + phase, reads the FID, writes the spectrum)
-Nothing is skipped or cached between steps.  Workload at N=1: BASELINE.json configs[2]
+Nothing is skipped or cached between steps.  Steps are independent datasets, so by default the
+pre-pass kernel of step i+1 is queued while the host solves step i (`--no-overlap` serialises them).  Workload at N=1: BASELINE.json configs[2]
 (65,536 voxels x 4096-pt complex64 FIDs zero-filled to 8192).  With --gpus N every rank owns its
 own 65,536-voxel shard of ONE dataset (weak scaling); the only cross-rank traffic is the O(1)
 arg-max exchange and the (p0, p1) broadcast.
@@ -64,6 +65,8 @@ def main():
     ap.add_argument("--lb", type=float, default=5.0)
     ap.add_argument("--dtype", choices=["c64", "c128"], default="c64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="do not queue the next step's pre-pass while the host solves the current one")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -100,59 +103,83 @@ def main():
     freq = np.roll(np.fft.fftfreq(N, d=tt[1] - tt[0]), N // 2)
 
     out = torch.empty((nv, N), dtype=cdtype, device=device)
-    absmax2 = torch.empty(nv, dtype=rdtype, device=device)
-    argidx = torch.empty(nv, dtype=torch.int32, device=device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    # two sets of pre-pass outputs: step i+1's pre-pass is queued while the host solves step i
+    absmax2 = [torch.empty(nv, dtype=rdtype, device=device) for _ in range(2)]
+    argidx = [torch.empty(nv, dtype=torch.int32, device=device) for _ in range(2)]
+    n_ev = max(args.steps, args.warmup, 1) + 1
+    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for k in ("pre0", "pre1", "main0", "main1")}
     times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": []}
     last = {}
 
     plan = pipeline.make_plan(x, t, N, args.lb)
     assert np.array_equal(plan.freq, freq)
     ddev = device if dist is not None else "cpu"
+    overlap = not args.no_overlap
+    sel = [None, None]
 
-    def step(record):
-        ev[0].record()
-        dev.pipeline_fused(x, N, 0, window=plan.window, want_out=False, want_argmax=True, absmax2=absmax2,
-                           argidx=argidx)
-        ev[1].record()
-        t0 = time.perf_counter()
-        state = {}
+    def prepass(i):
+        b = i & 1
+        ev["pre0"][i].record()
+        dev.pipeline_fused(x, N, 0, window=plan.window, want_out=False, want_argmax=True, absmax2=absmax2[b],
+                           argidx=argidx[b])
+        ev["pre1"][i].record()
+        # selection stage queued right behind it (device-side arg-max -> fp64 slice -> pinned host copies)
+        sel[b] = pipeline.Selection(x, plan, absmax2[b], argidx[b])
 
-        def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
-            state["t_x0"] = time.perf_counter()
-            owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev)
-            state["owner"] = owner
-            state["t_x1"] = time.perf_counter()
-            return owner == rank, gwin
+    def run_steps(n_steps, record):
+        """n_steps complete passes of the hot path.  Datasets are independent, so with `overlap` the
+        device runs the pre-pass of dataset i+1 (and the main pass of dataset i-1) while the host searches
+        (p0, p1) for dataset i; every step still does all of its own work inside this call (no pre-pass is
+        left over or reused).  NB: `out` is rewritten by every step (same synthetic dataset each time)."""
+        prepass(0)
+        for i in range(n_steps):
+            b = i & 1
+            t0 = time.perf_counter()
+            state = {}
 
-        res, mine = pipeline.select_and_solve(x, plan, absmax2, argidx, exchange=exchange, rank_offset_rows=rank * nv)
-        p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev)
-        t2 = time.perf_counter()
-        ph = torch.from_numpy(aps.phase_table(plan.freq, p0, p1, res.pivot)).to(device=device, dtype=cdtype)
-        ev[2].record()
-        dev.pipeline_fused(x, N, 0, window=plan.window, phase_table=ph, out=out)
-        ev[3].record()
-        last.update(p0=p0, p1=p1, pivot=res.pivot, flat=res.flat_index, owner=state["owner"])
-        if mine:
-            last["nfev"] = res.nfev
-        if record:
+            def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
+                owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev)
+                state["owner"] = owner
+                state["t_x1"] = time.perf_counter()
+                return owner == rank, gwin
+
+            def queue_next():
+                if overlap and i + 1 < n_steps:
+                    prepass(i + 1)
+
+            res, mine = pipeline.select_and_solve(x, plan, absmax2[b], argidx[b], exchange=exchange,
+                                                  rank_offset_rows=rank * nv, on_host_phase=queue_next,
+                                                  selection=sel[b])
+            p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev)
+            t2 = time.perf_counter()
+            ph = torch.from_numpy(aps.phase_table(plan.freq, p0, p1, res.pivot)).to(device=device, dtype=cdtype)
+            ev["main0"][i].record()
+            dev.pipeline_fused(x, N, 0, window=plan.window, phase_table=ph, out=out)
+            ev["main1"][i].record()
+            if not overlap and i + 1 < n_steps:
+                prepass(i + 1)
+            last.update(p0=p0, p1=p1, pivot=res.pivot, flat=res.flat_index, owner=state["owner"])
+            if mine:
+                last["nfev"] = res.nfev
+            if record:
+                times["exchange_ms"].append((state["t_x1"] - t0) * 1e3)
+                times["solve_ms"].append((t2 - state["t_x1"]) * 1e3)
+        if record:  # kernel durations are read after the loop so that no step waits for its own main pass
             torch.cuda.synchronize()
-            times["pre_ms"].append(ev[0].elapsed_time(ev[1]))
-            times["main_ms"].append(ev[2].elapsed_time(ev[3]))
-            times["exchange_ms"].append((state["t_x1"] - t0) * 1e3)
-            times["solve_ms"].append((t2 - state["t_x1"]) * 1e3)
+            for i in range(n_steps):
+                times["pre_ms"].append(ev["pre0"][i].elapsed_time(ev["pre1"][i]))
+                times["main_ms"].append(ev["main0"][i].elapsed_time(ev["main1"][i]))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    if args.warmup:
+        run_steps(args.warmup, False)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -199,6 +226,8 @@ def main():
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
         "autophase": {k: last.get(k) for k in ("p0", "p1", "pivot", "flat", "owner", "nfev")},
+        "schedule": ("pre-pass of step i+1 overlaps the host solve of step i (independent datasets)" if overlap
+                     else "strictly serial steps"),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

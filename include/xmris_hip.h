@@ -88,6 +88,12 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
 int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch, int n, void* out_max2,
                      int64_t* out_flat, int dtype, void* stream);
 
+/* A6  the ONE spectrum through the global maximum (phasing.py:241-242 `da.isel(...)`), fetched without a host
+ * round trip: out[j] = (complex128) in[row, j], j < n_in, with row = flat_index[0] / n_per_row read from DEVICE
+ * memory (the output of xm_argmax_reduce).  Feeds the complex128 recomputation of that spectrum for the solver. */
+int xm_gather_row_c128(const void* in, int64_t in_row_stride, int n_in, const int64_t* flat_index, int n_per_row,
+                       void* out, int dtype, void* stream);
+
 /* The fused hot path, one launch:
  *   z[j]   = (pad_left <= j < pad_left + n_in) ? in[b, j - pad_left] * window[j] : 0   (A1+A2)
  *   X      = FFT_n_out(z) * scale, optionally rolled                                    (A3+A4)

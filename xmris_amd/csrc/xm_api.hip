@@ -276,6 +276,23 @@ int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch
   return XM_OK;
 }
 
+int xm_gather_row_c128(const void* in, int64_t in_row_stride, int n_in, const int64_t* flat_index, int n_per_row,
+                       void* out, int dtype, void* stream) {
+  if (!in || !flat_index || !out || n_in < 1 || n_per_row < 1 || in_row_stride < n_in)
+    return fail(XM_ERR_INVALID_ARG, "gather_row: null pointer or bad geometry");
+  if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (n_in + 255) / 256;
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_gather_row<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in,
+                       (long long)in_row_stride, n_in, (const long long*)flat_index, n_per_row, (Cx<double>*)out);
+  else
+    hipLaunchKernelGGL(k_gather_row<double>, dim3(grid), dim3(256), 0, st, (const Cx<double>*)in,
+                       (long long)in_row_stride, n_in, (const long long*)flat_index, n_per_row, (Cx<double>*)out);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
 int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const void* window,
                       const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
                       void* absmax2, int32_t* argidx, int dtype, void* stream) {

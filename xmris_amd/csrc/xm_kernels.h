@@ -445,6 +445,18 @@ __global__ void k_roll(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, lo
   }
 }
 
+// out[j] = (complex128) in[row, j] for the row that holds the global arg-max, row = *flat / n_per_row.
+// The row index is read from device memory so that the arg-max spectrum can be recomputed in complex128
+// without a host round trip between the arg-max reduction and this gather.
+template <class T>
+__global__ void k_gather_row(const Cx<T>* __restrict__ in, long long in_stride, int n_in,
+                             const long long* __restrict__ flat, int n_per_row, Cx<double>* __restrict__ out) {
+  const long long row = flat[0] / n_per_row;
+  const Cx<T>* src = in + row * in_stride;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_in; j += gridDim.x * blockDim.x)
+    out[j] = mk<double>((double)src[j].re, (double)src[j].im);
+}
+
 // one 256-thread workgroup per spectrum
 template <class T>
 __global__ __launch_bounds__(256) void k_absmax_rows(const Cx<T>* __restrict__ in, long long n_batch, int n,

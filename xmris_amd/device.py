@@ -244,6 +244,33 @@ def argmax_reduce(absmax2, argidx, n: int):
     return float(gmax.item()) ** 0.5, int(gflat.item())
 
 
+def argmax_reduce_async(absmax2, argidx, n: int, gmax=None, gflat=None):
+    """Same reduction, results left on the device (no host synchronisation)."""
+    torch = _torch()
+    nb = absmax2.numel()
+    if gmax is None:
+        gmax = torch.empty(1, dtype=absmax2.dtype, device=absmax2.device)
+    if gflat is None:
+        gflat = torch.empty(1, dtype=torch.int64, device=absmax2.device)
+    code = _lib.XM_C64 if absmax2.dtype == torch.float32 else _lib.XM_C128
+    _lib.call("xm_argmax_reduce", absmax2.data_ptr(), argidx.data_ptr(), nb, n, gmax.data_ptr(),
+              gflat.data_ptr(), code, torch.cuda.current_stream(absmax2.device).cuda_stream)
+    return gmax, gflat
+
+
+def gather_row_c128(x2, gflat, n_per_row: int, out=None):
+    """phasing.py:241-242: the spectrum's source row, selected by a flat index that lives on the DEVICE,
+    upcast to complex128 ([1, n_in])."""
+    _require_device(x2)
+    torch = _torch()
+    nb, n_in = x2.shape
+    if out is None:
+        out = torch.empty((1, n_in), dtype=torch.complex128, device=x2.device)
+    _lib.call("xm_gather_row_c128", x2.data_ptr(), n_in, n_in, gflat.data_ptr(), int(n_per_row), out.data_ptr(),
+              _dtype_code(x2), _stream(x2))
+    return out
+
+
 def fft_supported(n: int, complex128: bool = False) -> bool:
     if n == 1:
         return True

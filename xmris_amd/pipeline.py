@@ -34,6 +34,7 @@ class PipelinePlan:
     freq: np.ndarray          # fftshifted frequency coordinate (fourier.py:98, 31-32)
     window_host: np.ndarray   # exp(-pi*lb*t) in fp64 (fid.py:136) or ones
     window: object = None     # device tensor, storage precision
+    window64: object = None   # device tensor, float64 (for the complex128 recomputation of the arg-max slice)
     extra: dict = field(default_factory=dict)
 
 
@@ -81,12 +82,51 @@ class AutophaseResult:
     fun: float = float("nan")
 
 
+class Selection:
+    """Device-side selection stage of autophase, queued without any host synchronisation right behind a
+    pre-pass: global arg-max reduction -> gather of the winning FID (row index read from device memory)
+    -> its spectrum recomputed in complex128 -> asynchronous copies of (max, flat index, slice) into
+    pinned host memory, closed by an event.  `wait()` blocks on that event only, so kernels queued
+    later on the same stream (another dataset's main pass) do not delay the host solver."""
+
+    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx):
+        import torch
+
+        n = plan.n_out
+        if plan.window64 is None:
+            plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
+        self.n = n
+        self.gmax, self.gflat = dev.argmax_reduce_async(absmax2, argidx, n)
+        x1 = dev.gather_row_c128(x2, self.gflat, n)
+        sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out
+        self.h_max = torch.empty(1, dtype=self.gmax.dtype, pin_memory=True)
+        self.h_flat = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        self.h_slice = torch.empty(n, dtype=torch.complex128, pin_memory=True)
+        self.h_max.copy_(self.gmax, non_blocking=True)
+        self.h_flat.copy_(self.gflat, non_blocking=True)
+        self.h_slice.copy_(sl[0], non_blocking=True)
+        self._keep = (x1, sl)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def wait(self):
+        self.event.synchronize()
+        return float(self.h_max.item()) ** 0.5, int(self.h_flat.item()), self.h_slice.numpy()
+
+
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
-                     p0_only=False, exchange=None, rank_offset_rows=0, disp=False):
+                     p0_only=False, exchange=None, rank_offset_rows=0, disp=False, on_host_phase=None,
+                     selection: "Selection | None" = None):
     """phasing.py:226-287 on the outputs of the pre-pass.  `exchange(max_abs, flat)` may merge the
-    per-rank winners (returns (owner_is_me, global_flat)); default = single device."""
+    per-rank winners (returns (owner_is_me, global_flat)); default = single device.
+    `on_host_phase()` is called once the device has nothing left to do for this dataset until the
+    solver returns (a streaming caller queues the next dataset's pre-pass there)."""
     n = plan.n_out
-    amax, flat = dev.argmax_reduce(absmax2, argidx, n)
+    sl_ready = None
+    if selection is not None:  # everything was queued behind the pre-pass already
+        amax, flat, sl_ready = selection.wait()
+    else:
+        amax, flat = dev.argmax_reduce(absmax2, argidx, n)
     gflat = rank_offset_rows * n + flat
     mine = True
     if exchange is not None:
@@ -105,13 +145,22 @@ def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", pea
         # recomputed in complex128 from the stored samples, as the reference's float64 path would.
         import torch
 
-        row = gflat // n - rank_offset_rows
-        x1 = x2[row:row + 1].to(torch.complex128)
-        w64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
-        sl = dev.pipeline_fused(x1, n, plan.pad_left, window=w64).out[0].cpu().numpy()
+        if sl_ready is not None:
+            sl = sl_ready
+        else:
+            row = gflat // n - rank_offset_rows
+            x1 = x2[row:row + 1].to(torch.complex128)
+            if plan.window64 is None:
+                plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
+            w64 = plan.window64
+            sl = dev.pipeline_fused(x1, n, plan.pad_left, window=w64).out[0].cpu().numpy()
+        if on_host_phase is not None:
+            on_host_phase()
         iw = aps.index_width_of(plan.freq, peak_width)
         p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp)
         res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
+    elif on_host_phase is not None:
+        on_host_phase()
     return res, mine
 
 
@@ -127,8 +176,12 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
         plan = make_plan(x2, t, target_points, lb)
     n = plan.n_out
     pre = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True)
-    res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only) \
-        if params is None else (_selection_only(pre, plan, target_coord), True)
+    if params is None:  # arg-max reduction, row gather, fp64 slice and D2H all queued without host syncs
+        sel = Selection(x2, plan, pre.absmax2, pre.argidx)
+        res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only,
+                                  selection=sel)
+    else:
+        res = _selection_only(pre, plan, target_coord)
     if params is not None:
         res.p0, res.p1 = float(params[0]), float(params[1])
     table = aps.phase_table(plan.freq, res.p0, res.p1, res.pivot)
