@@ -15,6 +15,42 @@
 
 namespace {
 
+// One 256-sample chunk of the ACME objective.  Built twice (function multi-versioning): AVX-512 for
+// CPUs that have it (8-wide libmvec sin/cos/log), AVX2 otherwise; the dispatcher picks at load time.
+__attribute__((target_clones("avx512f", "default"))) void acme_chunk_kernel(
+    const double* __restrict__ re, const double* __restrict__ im, const double* __restrict__ u, int nn, int c0,
+    double p0r, double p1r, double* __restrict__ pc) {
+  const int c1 = std::min(nn, c0 + 256);
+  double d[257], cs[257], sn[257];
+  const int m = std::min(nn, c1 + 1) - c0;  // one extra sample for the forward difference
+  // separate loops so that gcc uses the libmvec vector cos / sin (a fused sincos call stays scalar)
+#pragma omp simd
+  for (int k = 0; k < m; ++k) cs[k] = std::cos(p0r + p1r * u[c0 + k]);
+#pragma omp simd
+  for (int k = 0; k < m; ++k) sn[k] = std::sin(p0r + p1r * u[c0 + k]);
+#pragma omp simd
+  for (int k = 0; k < m; ++k) d[k] = re[c0 + k] * cs[k] - im[c0 + k] * sn[k];
+  double a_ds = 0, a_dl = 0, a_as = 0, a_as2 = 0, a_mx = -DBL_MAX;
+#pragma omp simd reduction(+ : a_ds, a_dl, a_as, a_as2) reduction(max : a_mx)
+  for (int k = 0; k < c1 - c0; ++k) {
+    const double v = d[k];
+    const double as_ = v - std::fabs(v);
+    a_as += as_;
+    a_as2 += (0.5 * as_) * (0.5 * as_);
+    a_mx = std::max(a_mx, v);
+    if (c0 + k + 1 < nn) {
+      const double ds = std::fabs((d[k + 1] - v) * 0.5);
+      a_ds += ds;
+      a_dl += ds > 0 ? ds * std::log(ds) : 0.0;
+    }
+  }
+  pc[0] = a_ds;
+  pc[1] = a_dl;
+  pc[2] = a_as;
+  pc[3] = a_as2;
+  pc[4] = a_mx;
+}
+
 struct Solver {
   int n = 0, method = 0, target_idx = 0, index_width = 1;
   double pivot = 0, x_range = 0;
@@ -30,35 +66,7 @@ struct Solver {
 
   // partial sums of one 256-sample chunk: {sum ds, sum ds*ln ds, sum a, sum (a/2)^2, max d}
   void acme_chunk(int c0, double p0r, double p1r, double* pc) const {
-    const int nn = n, c1 = std::min(nn, c0 + 256);
-    double d[257], cs[257], sn[257];
-    const int m = std::min(nn, c1 + 1) - c0;  // one extra sample for the forward difference
-    // separate loops so that gcc uses the libmvec vector cos / sin (a fused sincos call stays scalar)
-#pragma omp simd
-    for (int k = 0; k < m; ++k) cs[k] = std::cos(p0r + p1r * u[c0 + k]);
-#pragma omp simd
-    for (int k = 0; k < m; ++k) sn[k] = std::sin(p0r + p1r * u[c0 + k]);
-#pragma omp simd
-    for (int k = 0; k < m; ++k) d[k] = re[c0 + k] * cs[k] - im[c0 + k] * sn[k];
-    double a_ds = 0, a_dl = 0, a_as = 0, a_as2 = 0, a_mx = -DBL_MAX;
-#pragma omp simd reduction(+ : a_ds, a_dl, a_as, a_as2) reduction(max : a_mx)
-    for (int k = 0; k < c1 - c0; ++k) {
-      const double v = d[k];
-      const double as_ = v - std::fabs(v);
-      a_as += as_;
-      a_as2 += (0.5 * as_) * (0.5 * as_);
-      a_mx = std::max(a_mx, v);
-      if (c0 + k + 1 < nn) {
-        const double ds = std::fabs((d[k + 1] - v) * 0.5);
-        a_ds += ds;
-        a_dl += ds > 0 ? ds * std::log(ds) : 0.0;
-      }
-    }
-    pc[0] = a_ds;
-    pc[1] = a_dl;
-    pc[2] = a_as;
-    pc[3] = a_as2;
-    pc[4] = a_mx;
+    acme_chunk_kernel(re.data(), im.data(), u.data(), n, c0, p0r, p1r, pc);
   }
 
   double acme(double p0r, double p1r) const;  // phasing.py:100-122, one pass (defined after Pool)
