@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not queue the next step's pre-pass while the host solves the current one")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --share-gpu) to exercise "
+                         "the multi-rank code path on a single-GPU box; the driver uses the default (RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -82,14 +86,23 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    host_group = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL: barrier / timing reductions
+        else:
+            dist.init_process_group(args.dist_backend)
+        # the O(1) arg-max exchange and (p0, p1) broadcast are host-side metadata: a gloo group keeps
+        # them from queueing behind the kernels of other datasets already on the GPU stream
+        host_group = dist.new_group(backend="gloo")
 
     cdtype = torch.complex64 if args.dtype == "c64" else torch.complex128
     rdtype = torch.float32 if args.dtype == "c64" else torch.float64
@@ -113,7 +126,7 @@ def main():
 
     plan = pipeline.make_plan(x, t, N, args.lb)
     assert np.array_equal(plan.freq, freq)
-    ddev = device if dist is not None else "cpu"
+    ddev = "cpu"
     overlap = not args.no_overlap
     sel = [None, None]
 
@@ -138,7 +151,7 @@ def main():
             state = {}
 
             def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
-                owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev)
+                owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev, group=host_group)
                 state["owner"] = owner
                 state["t_x1"] = time.perf_counter()
                 return owner == rank, gwin
@@ -150,7 +163,7 @@ def main():
             res, mine = pipeline.select_and_solve(x, plan, absmax2[b], argidx[b], exchange=exchange,
                                                   rank_offset_rows=rank * nv, on_host_phase=queue_next,
                                                   selection=sel[b])
-            p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev)
+            p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev, group=host_group)
             t2 = time.perf_counter()
             ph = torch.from_numpy(aps.phase_table(plan.freq, p0, p1, res.pivot)).to(device=device, dtype=cdtype)
             ev["main0"][i].record()
@@ -183,7 +196,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

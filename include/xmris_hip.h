@@ -117,7 +117,7 @@ void xm_solver_destroy(void* solver);
 /* objective value at x = (p0[, p1]) in degrees */
 double xm_solver_score(void* solver, const double* x, int nx);
 long xm_solver_nfev(void* solver);
-/* team size of one objective evaluation inside xm_solver_de (<= 0: min(12, hardware threads / 2); 1 = serial);
+/* team size of one objective evaluation inside xm_solver_de (<= 0: min(16, hardware threads / 2); 1 = serial);
  * returns the value set.  Outside xm_solver_de evaluations are always serial. */
 int xm_solver_set_threads(void* solver, int threads);
 /* the differential-evolution generations (no polish); returns 0 = converged, 1 = maxiter reached */

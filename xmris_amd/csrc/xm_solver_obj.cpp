@@ -114,6 +114,7 @@ struct Solver {
 };
 
 
+
 // A few persistent worker threads that SPIN while a search is running (activated by xm_solver_de via
 // Pool::Scope) and sleep on a condition variable otherwise.  One evaluation = publish (p0, p1), bump a
 // generation counter, every thread does its chunks, the caller combines the per-chunk partial sums
@@ -175,6 +176,8 @@ struct Pool {
       th.emplace_back([this, id] { worker(id); });
     }
   }
+  // (No CPU pinning: on the shared MI355X hosts the scheduler finds idle cores better than a static
+  // same-L3 placement did -- measured 2.6 us vs 4.7 us per evaluation with 16 threads.)
   void activate() {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -254,7 +257,7 @@ void* xm_solver_create(const double* slice_re_im, const double* coords, int n, d
   }
   s->x_range = cmax - cmin;
   const int hw = (int)std::thread::hardware_concurrency();
-  s->threads = std::max(1, std::min(12, hw / 2));
+  s->threads = std::max(1, std::min(16, hw / 2));
   for (int k = 0; k < n; ++k) {
     s->re[k] = slice_re_im[2 * k];
     s->im[k] = slice_re_im[2 * k + 1];
@@ -269,13 +272,13 @@ double xm_solver_score(void* h, const double* x, int nx) { return ((Solver*)h)->
 
 long xm_solver_nfev(void* h) { return ((Solver*)h)->nfev; }
 
-// Team size of one objective evaluation: threads <= 0 picks min(12, hardware threads / 2), 1 = serial.
+// Team size of one objective evaluation: threads <= 0 picks min(16, hardware threads / 2), 1 = serial.
 // The team only engages between xm_solver_pool_begin() and xm_solver_pool_end() (workers spin then);
 // outside that window every evaluation is serial, which is what isolated calls from Python want.
 int xm_solver_set_threads(void* h, int threads) {
   if (threads <= 0) {
     const int hw = (int)std::thread::hardware_concurrency();
-    threads = std::max(1, std::min(12, hw / 2));
+    threads = std::max(1, std::min(16, hw / 2));
   }
   ((Solver*)h)->threads = std::min(threads, Pool::kMaxWorkers + 1);
   return threads;

@@ -26,9 +26,11 @@ def pick_winner(pairs):
     return best_r, int(best[1]), float(best[0])
 
 
-def exchange_argmax(max_abs: float, global_flat: int, dist=None, device="cpu"):
+def exchange_argmax(max_abs: float, global_flat: int, dist=None, device="cpu", group=None):
     """All ranks learn the winner.  `dist` = an initialised torch.distributed module (or None for a
-    single process).  Works on RCCL ("nccl", GPU tensors) and gloo (CPU tensors)."""
+    single process).  Works on RCCL ("nccl", GPU tensors) and gloo (CPU tensors, `group` = a gloo
+    process group).  For a streaming pipeline prefer a gloo group: an RCCL collective is ordered behind
+    everything already queued on the GPU (other datasets' kernels), a 32-byte host exchange is not."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return 0, int(global_flat), float(max_abs)
     import torch
@@ -39,7 +41,7 @@ def exchange_argmax(max_abs: float, global_flat: int, dist=None, device="cpu"):
     mine = torch.tensor([torch.tensor(max_abs, dtype=torch.float64).view(torch.int64).item(), int(global_flat)],
                         dtype=torch.int64, device=device)
     allv = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(allv, mine)
+    dist.all_gather(allv, mine, group=group)
     pairs = []
     for a in allv:
         a = a.cpu()
@@ -47,12 +49,12 @@ def exchange_argmax(max_abs: float, global_flat: int, dist=None, device="cpu"):
     return pick_winner(pairs)
 
 
-def broadcast_params(values, owner: int, dist=None, device="cpu"):
+def broadcast_params(values, owner: int, dist=None, device="cpu", group=None):
     """Broadcast a short list of float64 parameters (p0, p1) from `owner` to every rank."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [float(v) for v in values]
     import torch
 
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    dist.broadcast(t, src=owner)
+    dist.broadcast(t, src=owner, group=group)
     return [float(v) for v in t.cpu()]
