@@ -32,11 +32,10 @@ struct PipeArgs {
 
 // ---- (value, index) arg-max helpers: larger value wins, ties -> smaller index -------------------
 template <class T>
-XM_DEV void amax_take(T& bv, int& bi, T v, int i) {
-  if (v > bv || (v == bv && i < bi)) {
-    bv = v;
-    bi = i;
-  }
+XM_DEV void amax_take(T& bv, int& bi, T v, int i) {  // branch-free
+  const bool take = (v > bv) | ((v == bv) & (i < bi));
+  bv = take ? v : bv;
+  bi = take ? i : bi;
 }
 
 template <class T>
@@ -44,39 +43,92 @@ XM_DEV T shfl_xor_t(T v, int m) {
   return __shfl_xor(v, m, XM_WAVE);
 }
 
-// Reduce (bv, bi) over the NT threads that hold one spectrum and let its thread t == 0 write the
-// result.  NT is a power of two; `red` is LDS scratch for the NT > 64 case (>= blockDim/64 entries
-// of each kind); the function contains workgroup barriers when NT > 64.
+// DPP controls (gfx9): within a 16-lane row, then across rows
+#define XM_DPP_QUAD_XOR1 0xB1     // quad_perm:[1,0,3,2]
+#define XM_DPP_QUAD_XOR2 0x4E     // quad_perm:[2,3,0,1]
+#define XM_DPP_HALF_MIRROR 0x141  // row_half_mirror
+#define XM_DPP_ROW_MIRROR 0x140   // row_mirror
+#define XM_DPP_BCAST15 0x142      // row_bcast:15
+#define XM_DPP_BCAST31 0x143      // row_bcast:31
+
+// Wave-wide (64 lanes) reduction of a 32-bit unsigned key with v_max_u32 / v_min_u32 through DPP: six
+// VALU instructions and no LDS round trips (a __shfl_xor butterfly costs six ds_bpermute latencies).
+// Non-negative floats order like their bit patterns, so |X|^2 is reduced as an unsigned key.
+template <bool MAX>
+XM_DEV unsigned wave_reduce_u32(unsigned v) {
+  auto op = [](unsigned a, unsigned b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  const unsigned ident = MAX ? 0u : 0xffffffffu;
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_QUAD_XOR1, 0xf, 0xf, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_QUAD_XOR2, 0xf, 0xf, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_HALF_MIRROR, 0xf, 0xf, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_ROW_MIRROR, 0xf, 0xf, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_BCAST15, 0xa, 0xf, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_BCAST31, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// (max value, first index) over the 64 lanes of a wave; result uniform across the wave
+XM_DEV void wave_amax(float& bv, int& bi) {
+  const unsigned key = __float_as_uint(bv);  // bv >= 0 (a squared magnitude) or -1 for "nothing"
+  const unsigned kmax = wave_reduce_u32<true>(bv < 0.f ? 0u : key);
+  const unsigned cand = (bv >= 0.f && key == kmax) ? (unsigned)bi : 0xffffffffu;
+  bi = (int)wave_reduce_u32<false>(cand);
+  bv = __uint_as_float(kmax);
+}
+XM_DEV void wave_amax(double& bv, int& bi) {  // not on the hot path: shuffle butterfly
+#pragma unroll
+  for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
+    const double ov = shfl_xor_t(bv, m);
+    const int oi = __shfl_xor(bi, m, XM_WAVE);
+    amax_take(bv, bi, ov, oi);
+  }
+}
+
+// Reduce (bv, bi) over the NT threads that hold one spectrum and let one thread write the result.
+// NT is a power of two.  NT <= 64: shuffle butterfly inside the NT-lane group.  NT > 64: DPP wave
+// reduction, one LDS slot per wave, ONE workgroup barrier, then the spectrum's first wave combines the
+// NT/64 slots.  `red_v` / `red_i` must be LDS that nothing else writes until the next barrier.
 template <class T, int NT>
 XM_DEV void amax_reduce_store(T bv, int bi, int t, bool live, long long s, T* absmax2, int32_t* argidx,
                               T* red_v, int* red_i) {
-  constexpr int W = NT < XM_WAVE ? NT : XM_WAVE;
-#pragma unroll
-  for (int m = W / 2; m >= 1; m >>= 1) {
-    T ov = shfl_xor_t(bv, m);
-    int oi = __shfl_xor(bi, m, XM_WAVE);
-    amax_take(bv, bi, ov, oi);
-  }
   if constexpr (NT <= XM_WAVE) {
+#pragma unroll
+    for (int m = NT / 2; m >= 1; m >>= 1) {
+      T ov = shfl_xor_t(bv, m);
+      int oi = __shfl_xor(bi, m, XM_WAVE);
+      amax_take(bv, bi, ov, oi);
+    }
     if (t == 0 && live) {
       absmax2[s] = bv;
       argidx[s] = bi;
     }
   } else {
     constexpr int NW = NT / XM_WAVE;  // waves per spectrum
-    const int wave = threadIdx.x / XM_WAVE;
-    __syncthreads();  // the exchange buffer is free again
-    if ((threadIdx.x & (XM_WAVE - 1)) == 0) {
+    const int wave = threadIdx.x / XM_WAVE, lane = threadIdx.x & (XM_WAVE - 1);
+    wave_amax(bv, bi);
+    if (lane == 0) {
       red_v[wave] = bv;
       red_i[wave] = bi;
     }
     __syncthreads();
-    if (t == 0 && live) {
-      const int w0 = wave;  // first wave of this spectrum
+    if (t < XM_WAVE) {  // first wave of this spectrum (t == lane there)
+      const int w0 = wave;
+      T v = T(-1);
+      int i = 0x7fffffff;
+      if (lane < NW) {
+        v = red_v[w0 + lane];
+        i = red_i[w0 + lane];
+      }
 #pragma unroll
-      for (int w = 1; w < NW; ++w) amax_take(bv, bi, red_v[w0 + w], red_i[w0 + w]);
-      absmax2[s] = bv;
-      argidx[s] = bi;
+      for (int m = (NW > 1 ? NW / 2 : 0); m >= 1; m >>= 1) {
+        T ov = shfl_xor_t(v, m);
+        int oi = __shfl_xor(i, m, XM_WAVE);
+        amax_take(v, i, ov, oi);
+      }
+      if (lane == 0 && live) {
+        absmax2[s] = v;
+        argidx[s] = i;
+      }
     }
   }
 }
