@@ -160,6 +160,8 @@ CASES = [
     (3, 4096, 8192, 0),
     (6, 1000, 4096, 0),
     (6, 3000, 4096, 0),
+    (5, 700, 4096, 300),   # >=2x zero fill with a left pad: persistent kernel, clamped loads
+    (2, 4096, 16384, 0),   # half length 8192 (1024-thread workgroups), complex64 only
     (4, 32, 128, 48),
     (7, 1536, 1536, 0),
     (5, 1200, 1536, 0),
@@ -173,6 +175,9 @@ CASES = [
 @pytest.mark.parametrize("nb,n_in,n_out,pad_left", CASES)
 def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_left, dtype):
     import torch
+
+    if n_out == 16384 and dtype == "complex128":
+        pytest.skip("16384-point complex128 does not fit the LDS (documented limit)")
 
     x = _rand((nb, n_in), dtype, seed=n_in + n_out)
     x128 = x.astype(np.complex128)

@@ -10,8 +10,10 @@ int xm_fail(int code, const std::string& msg);
 #define HIP_TRY(expr)                                                                \
   do {                                                                               \
     hipError_t e_ = (expr);                                                          \
-    if (e_ != hipSuccess)                                                            \
+    if (e_ != hipSuccess) {                                                          \
+      (void)hipGetLastError(); /* clear the sticky error: the next call starts clean */ \
       return xm_fail(XM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                                \
   } while (0)
 
 enum XmTableKind { TK_TWIDDLE = 0, TK_HALF = 1, TK_CHIRP = 2, TK_CHIRP_FFT = 3 };

@@ -24,8 +24,7 @@
   X(512, 64, 8, 8, 8)         \
   X(1024, 128, 8, 8, 4, 4)    \
   X(2048, 256, 8, 8, 8, 4)    \
-  X(4096, 512, 8, 8, 8, 8)    \
-  X(8192, 1024, 8, 8, 8, 8, 2)
+  X(4096, 512, 8, 8, 8, 8)
 
 // tiny lengths and 3*2^k / 5*2^k lengths: generic kernel only
 #define XM_PLANS_OTHER(X)     \

@@ -99,9 +99,15 @@ class Selection:
         self.gmax, self.gflat = dev.argmax_reduce_async(absmax2, argidx, n)
         x1 = dev.gather_row_c128(x2, self.gflat, n)
         sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out
-        self.h_max = torch.empty(1, dtype=self.gmax.dtype, pin_memory=True)
-        self.h_flat = torch.empty(1, dtype=torch.int64, pin_memory=True)
-        self.h_slice = torch.empty(n, dtype=torch.complex128, pin_memory=True)
+        # pinned staging buffers are reused across datasets (two sets: a streaming caller keeps at most
+        # two selections in flight); allocating pinned memory per call costs more than the copies
+        pool = plan.extra.setdefault("pinned", [])
+        turn = plan.extra["turn"] = (plan.extra.get("turn", -1) + 1) % 2
+        if len(pool) <= turn:
+            pool.append((torch.empty(1, dtype=self.gmax.dtype, pin_memory=True),
+                         torch.empty(1, dtype=torch.int64, pin_memory=True),
+                         torch.empty(n, dtype=torch.complex128, pin_memory=True)))
+        self.h_max, self.h_flat, self.h_slice = pool[turn]
         self.h_max.copy_(self.gmax, non_blocking=True)
         self.h_flat.copy_(self.gflat, non_blocking=True)
         self.h_slice.copy_(sl[0], non_blocking=True)
@@ -111,7 +117,7 @@ class Selection:
 
     def wait(self):
         self.event.synchronize()
-        return float(self.h_max.item()) ** 0.5, int(self.h_flat.item()), self.h_slice.numpy()
+        return float(self.h_max.item()) ** 0.5, int(self.h_flat.item()), self.h_slice.numpy().copy()
 
 
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
