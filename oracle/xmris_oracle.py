@@ -548,6 +548,47 @@ def autophase(
 
 
 # ---------------------------------------------------------------------------
+# "next" (SURVEY 8f rank 3): Bruker digital-filter removal  (vendor/bruker.py:7-118)
+# ---------------------------------------------------------------------------
+def remove_digital_filter(da: Labeled, group_delay: float, dim: str = "time", keep_length: bool = True):
+    if dim not in da.dims:  # bruker.py:54-55
+        raise ValueError(f"Dimension '{dim}' missing in DataArray.")
+    if group_delay <= 0:  # bruker.py:57-58
+        return da.copy()
+    int_delay = int(np.floor(group_delay))  # bruker.py:61-63
+    frac_delay = group_delay - int_delay
+    ax = da.axis(dim)
+    sl = [slice(None)] * da.values.ndim
+    sl[ax] = slice(int_delay, None)
+    cut_vals = da.values[tuple(sl)] if int_delay > 0 else da.values  # bruker.py:66-69
+    cut_coords = {k: (Coord(c.dim, c.values[int_delay:], dict(c.attrs)) if (c.dim == dim and int_delay > 0)
+                      else Coord(c.dim, c.values.copy(), dict(c.attrs))) for k, c in da.coords.items()}
+    if not np.isclose(frac_delay, 0.0):  # bruker.py:72-86
+        n = cut_vals.shape[ax]
+        freqs = np.fft.fftfreq(n)
+        shape = [1] * cut_vals.ndim
+        shape[ax] = -1
+        spectrum = np.fft.fft(cut_vals, axis=ax)
+        corrector = np.exp(1j * 2 * np.pi * freqs.reshape(shape) * frac_delay)
+        corrected = np.fft.ifft(spectrum * corrector, axis=ax)
+    else:
+        corrected = cut_vals
+    if int_delay > 0 and keep_length:  # bruker.py:89-95
+        pad_shape = list(corrected.shape)
+        pad_shape[ax] = int_delay
+        final = np.concatenate((corrected, np.zeros(pad_shape, dtype=corrected.dtype)), axis=ax)
+        coords = {k: Coord(c.dim, c.values.copy(), dict(c.attrs)) for k, c in da.coords.items()}
+    else:
+        final, coords = corrected, cut_coords
+    out = Labeled(final, da.dims, coords, _copy.copy(da.attrs), da.name)
+    tc = out.coords[dim].values  # bruker.py:104-105 (KeyError without a coordinate)
+    out.coords[dim] = Coord(dim, tc - tc[0], dict(out.coords[dim].attrs))
+    out.attrs.update({"digital_filter_removed": True, "group_delay_removed": group_delay,
+                      "length_retained_with_zeros": keep_length})  # bruker.py:108-116
+    return out
+
+
+# ---------------------------------------------------------------------------
 # Array-level whole pipeline (the benchmark's CPU baseline issues exactly these calls)
 # ---------------------------------------------------------------------------
 def pipeline_values(x: np.ndarray, t: np.ndarray, target_points: int, lb: float,

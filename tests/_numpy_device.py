@@ -46,6 +46,17 @@ def fft(x, axis, inverse=False, ortho=True, shift_in=False, shift_out=False):
     return y
 
 
+def slice_axis(x, axis, start):
+    idx = [slice(None)] * x.ndim
+    idx[axis] = slice(int(start), None)
+    return np.ascontiguousarray(x[tuple(idx)])
+
+
+def shift_fractional(x, axis, start, table):
+    y = slice_axis(x, axis, start)
+    return np.fft.ifft(_along(np.fft.fft(y, axis=axis), table, axis), axis=axis)
+
+
 def absmax_argmax(x):
     flat = int(np.argmax(np.abs(x)))
     return float(np.abs(x).reshape(-1)[flat]), flat
@@ -54,5 +65,6 @@ def absmax_argmax(x):
 def install(monkeypatch):
     from xmris_amd import device
 
-    for name in ("to_device", "zero_fill", "apodize", "phase_apply", "roll", "fft", "absmax_argmax"):
+    for name in ("to_device", "zero_fill", "apodize", "phase_apply", "roll", "fft", "absmax_argmax", "slice_axis",
+                 "shift_fractional"):
         monkeypatch.setattr(device, name, globals()[name])

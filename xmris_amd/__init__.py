@@ -12,6 +12,7 @@ from .accessor import XmrisAccessor, register_xarray_accessor
 from .config import ATTRS, COORDS, DIMS
 from .fused import spectral_pipeline
 from .labeled import Coordinate, LabeledArray
+from .vendor.bruker import remove_digital_filter
 from .processing import (apodize_exp, apodize_lg, autophase, fft, fftc, fftshift, ifft, ifftc, ifftshift, phase,
                          to_fid, to_spectrum, zero_fill)
 
@@ -20,4 +21,4 @@ register_xarray_accessor()  # no-op when xarray is absent or the name `xmr` is a
 
 __all__ = ["ATTRS", "COORDS", "DIMS", "Coordinate", "DataArray", "LabeledArray", "XmrisAccessor",
            "apodize_exp", "apodize_lg", "autophase", "fft", "fftc", "fftshift", "ifft", "ifftc", "ifftshift",
-           "phase", "register_xarray_accessor", "spectral_pipeline", "to_fid", "to_spectrum", "zero_fill"]
+           "phase", "register_xarray_accessor", "remove_digital_filter", "spectral_pipeline", "to_fid", "to_spectrum", "zero_fill"]

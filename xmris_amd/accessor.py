@@ -65,6 +65,13 @@ class XmrisPhasingMixin:
                          temp_time_dim=temp_time_dim, **kwargs)
 
 
+class XmrisVendorMixin:
+    def remove_digital_filter(self, group_delay: float, dim: str = "time", keep_length: bool = True):
+        from .vendor.bruker import remove_digital_filter
+
+        return remove_digital_filter(self._obj, group_delay=group_delay, dim=dim, keep_length=keep_length)
+
+
 class XmrisFusedMixin:
     def spectral_pipeline(self, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,
                           out_dim: str = DIMS.frequency, method: str = "acme", peak_width: int = 100, **kwargs):
@@ -76,7 +83,7 @@ class XmrisFusedMixin:
                                  method=method, peak_width=peak_width, **kwargs)
 
 
-class XmrisAccessor(XmrisFourierMixin, XmrisProcessingMixin, XmrisPhasingMixin, XmrisFusedMixin):
+class XmrisAccessor(XmrisFourierMixin, XmrisProcessingMixin, XmrisPhasingMixin, XmrisVendorMixin, XmrisFusedMixin):
     """``obj.xmr.<method>`` for the hot-path methods."""
 
     def __init__(self, obj):

@@ -169,6 +169,38 @@ def fft(x, axis: int, inverse: bool = False, ortho: bool = True, shift_in: bool 
     return restore(out)
 
 
+def slice_axis(x, axis: int, start: int):
+    """``da.isel({dim: slice(start, None)})`` on the data (bruker.py:66-67): contiguous copy."""
+    _require_device(x)
+    idx = [slice(None)] * x.dim()
+    idx[axis % x.dim()] = slice(int(start), None)
+    return x[tuple(idx)].contiguous()
+
+
+def shift_fractional(x, axis: int, start: int, table):
+    """bruker.py:79-84 on rows that start at sample `start`:  ifft(fft(x[start:]) * table).
+
+    Two launches: the forward transform reads the rows in place (pointer offset + row stride, no slicing
+    copy) and multiplies by `table` (complex, n - start values, fp64-computed) on the way out; the
+    inverse transform carries numpy's 1/n scale."""
+    _require_device(x)
+    torch = _torch()
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    m = n - int(start)
+    ph = _table(table, x, complex_table=True)
+    if ph.numel() != m:
+        raise ValueError(f"table has {ph.numel()} points, sliced axis has {m}")
+    view = x2[:, int(start):]
+    spec = torch.empty((nb, m), dtype=x.dtype, device=x.device)
+    code, st = _dtype_code(x), _stream(x)
+    _lib.call("xm_pipeline_fused", view.data_ptr(), n, spec.data_ptr(), None, ph.data_ptr(), nb, m, m, 0, 0,
+              None, None, code, st)
+    out = torch.empty_like(spec)
+    _lib.call("xm_fft1d_batched", spec.data_ptr(), out.data_ptr(), nb, m, _lib.XM_FFT_INVERSE, code, st)
+    return restore(out)
+
+
 def absmax_argmax(x):
     """phasing.py:229 ``int(np.argmax(np.abs(values)))``: (max |x|, first flat C-order index).
 
