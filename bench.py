@@ -127,7 +127,7 @@ def main():
     argidx = [torch.empty(nv, dtype=torch.int32, device=device) for _ in range(2)]
     n_ev = max(args.steps, args.warmup, 1) + 1
     ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for k in ("pre0", "pre1", "main0", "main1")}
-    times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": []}
+    times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": [], "gen_ms": [], "polish_ms": [], "table_ms": []}
     last = {}
 
     plan = pipeline.make_plan(x, t, N, args.lb)
@@ -171,7 +171,8 @@ def main():
                                                   selection=sel[b])
             p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev, group=host_group)
             t2 = time.perf_counter()
-            ph = torch.from_numpy(aps.phase_table(plan.freq, p0, p1, res.pivot)).to(device=device, dtype=cdtype)
+            ph = pipeline.upload_phase_table(plan, x, p0, p1, res.pivot)
+            t3 = time.perf_counter()
             ev["main0"][i].record()
             dev.pipeline_fused(x, N, 0, window=plan.window, phase_table=ph, out=out)
             ev["main1"][i].record()
@@ -183,6 +184,10 @@ def main():
             if record:
                 times["exchange_ms"].append((state["t_x1"] - t0) * 1e3)
                 times["solve_ms"].append((t2 - state["t_x1"]) * 1e3)
+                times["table_ms"].append((t3 - t2) * 1e3)
+                if mine:
+                    times["gen_ms"].append(res.timing.get("generations_ms", 0.0))
+                    times["polish_ms"].append(res.timing.get("polish_ms", 0.0))
         if record:  # kernel durations are read after the loop so that no step waits for its own main pass
             torch.cuda.synchronize()
             for i in range(n_steps):
@@ -233,7 +238,7 @@ def main():
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_zf2<float, FftPlan<4096,512,8,8,8,8>, 3> (main pass: zero-fill+window+FFT+fftshift+phase)",
+            "bound": "hbm", "kernel": "k_zf2<float, FftPlan<4096,256,16,16,16>, 3> (main pass: zero-fill+window+FFT+fftshift+phase)",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None),
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01/pmc_main_kernel.txt",
@@ -243,6 +248,9 @@ def main():
             "prepass_kernel": pre_ms, "main_kernel": main_ms,
             "argmax_reduce_and_exchange": float(np.mean(times["exchange_ms"])),
             "slice_de_solve_broadcast": float(np.mean(times["solve_ms"])),
+            "solver_generations": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
+            "solver_polish": float(np.mean(times["polish_ms"])) if times["polish_ms"] else None,
+            "phase_table_and_upload": float(np.mean(times["table_ms"])),
             "streaming_spectra_per_s_per_gpu": nv / (stream_ms * 1e-3),
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },

@@ -124,8 +124,12 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
     `DifferentialEvolutionSolver.solve` does it."""
     import scipy.optimize
 
+    import time
+
+    t0 = time.perf_counter()
     obj = NativeObjective(sl, coords, pivot, target_idx, index_width, method)
     rc, x, fun, nfev, nit = obj.de(p0_only)  # worker pool spins for the duration of the generations
+    t1 = time.perf_counter()
     # the polish's isolated evaluations below run serially (the pool is parked outside xm_solver_de)
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
     res = scipy.optimize.minimize(obj, np.copy(x), method="L-BFGS-B", bounds=bounds)
@@ -135,7 +139,8 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
     polished = bool(res.fun < fun and res.success and np.all(res.x <= hi) and np.all(lo <= res.x))
     if polished:
         x, fun = res.x, float(res.fun)
-    opt = scipy.optimize.OptimizeResult(x=x, fun=fun, nfev=nfev, nit=nit, success=(rc == 0), polished=polished)
+    opt = scipy.optimize.OptimizeResult(x=x, fun=fun, nfev=nfev, nit=nit, success=(rc == 0), polished=polished,
+                                        t_generations=t1 - t0, t_polish=time.perf_counter() - t1)
     return opt
 
 

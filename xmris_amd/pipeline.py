@@ -80,6 +80,7 @@ class AutophaseResult:
     max_abs: float
     nfev: int = 0
     fun: float = float("nan")
+    timing: dict = field(default_factory=dict)
 
 
 class Selection:
@@ -165,6 +166,7 @@ def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", pea
         iw = aps.index_width_of(plan.freq, peak_width)
         p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp)
         res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
+        res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
     elif on_host_phase is not None:
         on_host_phase()
     return res, mine
@@ -190,10 +192,36 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
         res = _selection_only(pre, plan, target_coord)
     if params is not None:
         res.p0, res.p1 = float(params[0]), float(params[1])
-    table = aps.phase_table(plan.freq, res.p0, res.p1, res.pivot)
-    ph = torch.from_numpy(table).to(device=x2.device, dtype=x2.dtype)
+    ph = upload_phase_table(plan, x2, res.p0, res.p1, res.pivot)
     main = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, phase_table=ph, out=out)
     return main.out, res, plan
+
+
+def upload_phase_table(plan: PipelinePlan, like, p0: float, p1: float, pivot: float):
+    """e^{i phi} over the frequency axis (fp64 on the host, phasing.py:56-73), rounded once to the storage
+    precision into a reused pinned staging buffer and copied to the device asynchronously."""
+    import torch
+
+    n = plan.n_out
+    key = ("phase_stage", str(like.dtype))
+    stage = plan.extra.get(key)
+    if stage is None:
+        stage = plan.extra[key] = [torch.empty(n, dtype=like.dtype, pin_memory=True) for _ in range(2)] + [0]
+    stage[2] ^= 1
+    host = stage[stage[2]]
+    ang = aps.phase_angles(plan.freq, p0, p1, pivot)
+    view = host.numpy()
+    if np.ndim(ang) == 0:
+        view[:] = np.exp(1.0j * ang)
+    else:  # cos/sin straight into the staging buffer's (re, im) lanes: same values as np.exp(1j*ang)
+        pair = view.view(np.float32 if like.dtype == torch.complex64 else np.float64).reshape(n, 2)
+        pair[:, 0] = np.cos(ang)
+        pair[:, 1] = np.sin(ang)
+    dev_t = plan.extra.setdefault(("phase_dev", str(like.dtype)),
+                                  [torch.empty(n, dtype=like.dtype, device=like.device) for _ in range(2)])
+    out = dev_t[stage[2]]
+    out.copy_(host, non_blocking=True)
+    return out
 
 
 def _selection_only(pre, plan, target_coord):
