@@ -106,6 +106,16 @@ int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const vo
                       const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left,
                       unsigned flags, void* absmax2, int32_t* argidx, int dtype, void* stream);
 
+/* "next" (SURVEY 8f rank 4): asymmetric-least-squares baseline (processing/baseline.py:10-40 `_als_core`
+ * applied along the last axis by `xr.apply_ufunc`, :102-110).  For every spectrum: n_iter rounds of
+ * (W + lam*D'D) z = W y (pentadiagonal SPD, band LDL' in fp64) and w = p (y > z) + (1 - p) (y < z);
+ * out[b, j] = y[b, j] - z[b, j] in float64, y = the REAL part of the input (is_complex) or the input itself
+ * (real float32 / float64 for XM_C64 / XM_C128).  `workspace`: device scratch of
+ * xm_baseline_als_workspace_bytes(n_batch, n) bytes owned by the caller. */
+int64_t xm_baseline_als_workspace_bytes(int64_t n_batch, int n);
+int xm_baseline_als(const void* in, int is_complex, int64_t n_batch, int n, double lam, double p, int n_iter, void* out,
+                    void* workspace, int64_t workspace_bytes, int dtype, void* stream);
+
 /* ---- A7  host-side autophase search (no GPU involved; O(1) per dataset) ------------------------
  * Objectives of processing/phasing.py:100-157 and the differential-evolution driver the reference
  * reaches through scipy (phasing.py:276-284: best1bin, tol, seed, bounds p0 in [-180,180] deg,

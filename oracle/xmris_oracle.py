@@ -589,6 +589,35 @@ def remove_digital_filter(da: Labeled, group_delay: float, dim: str = "time", ke
 
 
 # ---------------------------------------------------------------------------
+# "next" (SURVEY 8f rank 4): AsLS baseline  (processing/baseline.py:10-119)
+# ---------------------------------------------------------------------------
+def als_core(y: np.ndarray, lam: float, p: float, n_iter: int) -> np.ndarray:
+    """baseline.py:10-40 -- same scipy.sparse calls."""
+    from scipy import sparse
+    from scipy.sparse.linalg import spsolve
+
+    L = len(y)
+    D = sparse.diags([1, -2, 1], [0, 1, 2], shape=(L - 2, L), dtype=float)
+    D_T_D = (lam * D.T.dot(D)).tocsc()
+    w = np.ones(L)
+    for _ in range(n_iter):
+        W = sparse.diags(w, 0, format="csc", dtype=float)
+        z = spsolve(W + D_T_D, w * y)
+        w = p * (y > z) + (1 - p) * (y < z)
+    return z
+
+
+def baseline_als(da: Labeled, dim: str = DIM_FREQUENCY, lam: float = 1e5, p: float = 0.001, n_iter: int = 10):
+    check_dims(da, dim, "baseline_als")  # baseline.py:92
+    work = np.real(da.values) if np.iscomplexobj(da.values) else da.values  # :95-96
+    base = np.apply_along_axis(als_core, da.axis(dim), work, lam, p, n_iter)  # :99-107 (apply_ufunc, vectorize)
+    out = da.copy(values=work - base)  # :110
+    out.attrs = _copy.copy(da.attrs)  # :113-119
+    out.attrs.update({"baseline_method": "als", "baseline_lam": lam, "baseline_p": p, "baseline_iter": n_iter})
+    return out
+
+
+# ---------------------------------------------------------------------------
 # Array-level whole pipeline (the benchmark's CPU baseline issues exactly these calls)
 # ---------------------------------------------------------------------------
 def pipeline_values(x: np.ndarray, t: np.ndarray, target_points: int, lb: float,

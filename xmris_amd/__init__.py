@@ -13,12 +13,12 @@ from .config import ATTRS, COORDS, DIMS
 from .fused import spectral_pipeline
 from .labeled import Coordinate, LabeledArray
 from .vendor.bruker import remove_digital_filter
-from .processing import (apodize_exp, apodize_lg, autophase, fft, fftc, fftshift, ifft, ifftc, ifftshift, phase,
+from .processing import (baseline_als, apodize_exp, apodize_lg, autophase, fft, fftc, fftshift, ifft, ifftc, ifftshift, phase,
                          to_fid, to_spectrum, zero_fill)
 
 DataArray = LabeledArray  # convenience alias for code written against xarray's constructor signature
 register_xarray_accessor()  # no-op when xarray is absent or the name `xmr` is already owned
 
-__all__ = ["ATTRS", "COORDS", "DIMS", "Coordinate", "DataArray", "LabeledArray", "XmrisAccessor",
+__all__ = ["baseline_als", "ATTRS", "COORDS", "DIMS", "Coordinate", "DataArray", "LabeledArray", "XmrisAccessor",
            "apodize_exp", "apodize_lg", "autophase", "fft", "fftc", "fftshift", "ifft", "ifftc", "ifftshift",
            "phase", "register_xarray_accessor", "remove_digital_filter", "spectral_pipeline", "to_fid", "to_spectrum", "zero_fill"]

@@ -45,6 +45,8 @@ SIGNATURES = {
     "xm_phase_apply": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "xm_absmax_rows": (_i, [_p, _l, _i, _p, _p, _i, _p]),
     "xm_argmax_reduce": (_i, [_p, _p, _l, _i, _p, _p, _i, _p]),
+    "xm_baseline_als_workspace_bytes": (_l, [_l, _i]),
+    "xm_baseline_als": (_i, [_p, _i, _l, _i, ctypes.c_double, ctypes.c_double, _i, _p, _p, _l, _i, _p]),
     "xm_gather_row_c128": (_i, [_p, _l, _i, _p, _i, _p, _i, _p]),
     "xm_pipeline_fused": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
     "xm_solver_create": (_p, [_p, _p, _i, ctypes.c_double, _i, _i, _i]),

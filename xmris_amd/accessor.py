@@ -52,6 +52,11 @@ class XmrisProcessingMixin:
     def zero_fill(self, dim: str = DIMS.time, target_points: int = 1024, position: str = "end"):
         return zero_fill(self._obj, dim=dim, target_points=target_points, position=position)
 
+    def baseline_als(self, dim: str = DIMS.frequency, lam: float = 1e5, p: float = 0.001, n_iter: int = 10):
+        from .processing.baseline import baseline_als
+
+        return baseline_als(self._obj, dim=dim, lam=lam, p=p, n_iter=n_iter)
+
 
 class XmrisPhasingMixin:
     def phase(self, dim: str = DIMS.frequency, p0: float = 0.0, p1: float = 0.0, pivot: float = None):

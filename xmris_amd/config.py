@@ -49,6 +49,10 @@ class _Attrs(_Vocabulary):
     apodization_gb = XmrisTerm("apodization_gb", "Gaussian broadening that was applied.", "Hz")
     zero_fill_target = XmrisTerm("zero_fill_target", "Number of points after zero filling.")
     zero_fill_position = XmrisTerm("zero_fill_position", "Where zeros were added: 'end' or 'symmetric'.")
+    baseline_method = XmrisTerm("baseline_method", "Algorithm that estimated the removed baseline.")
+    baseline_lam = XmrisTerm("baseline_lam", "Smoothness penalty of the AsLS baseline.")
+    baseline_p = XmrisTerm("baseline_p", "Asymmetry parameter of the AsLS baseline.")
+    baseline_iter = XmrisTerm("baseline_iter", "Number of AsLS re-weighting iterations.")
 
 
 class _Dims(_Vocabulary):

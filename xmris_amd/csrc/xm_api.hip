@@ -2,6 +2,7 @@
 // declared in include/xmris_hip.h.  gfx950 only.  The fused FFT kernels are instantiated per
 // storage precision in xm_launch_f32.hip / xm_launch_f64.hip.
 #include "xm_host.h"
+#include "xm_als.h"
 #include "xm_kernels.h"
 #include "xm_plans.h"
 
@@ -272,6 +273,44 @@ int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch
   else
     hipLaunchKernelGGL(k_argmax_final<double>, dim3(1), dim3(1024), 0, st, (const double*)absmax2, argidx,
                        (long long)n_batch, n, (double*)out_max2, (long long*)out_flat);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int64_t xm_baseline_als_workspace_bytes(int64_t n_batch, int n) {
+  if (n_batch < 0 || n < 0) return 0;
+  return 5 * n_batch * (int64_t)n * (int64_t)sizeof(double);
+}
+
+int xm_baseline_als(const void* in, int is_complex, int64_t n_batch, int n, double lam, double p, int n_iter, void* out,
+                    void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
+  if ((!in || !out || !workspace) && n_batch > 0) return fail(XM_ERR_INVALID_ARG, "baseline_als: null pointer");
+  if (n_batch < 0 || n < 3 || n_iter < 1) return fail(XM_ERR_INVALID_ARG, "baseline_als: needs n >= 3, n_iter >= 1");
+  if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
+  if (workspace_bytes < xm_baseline_als_workspace_bytes(n_batch, n))
+    return fail(XM_ERR_INVALID_ARG, "baseline_als: workspace too small (see xm_baseline_als_workspace_bytes)");
+  if (n_batch == 0) return XM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long long plane = (long long)n_batch * n;
+  double* yt = (double*)workspace;
+  double *zt = yt + plane, *l1t = yt + 2 * plane, *l2t = yt + 3 * plane, *vt = yt + 4 * plane;
+  const long long by = (n_batch + 31) / 32;
+  if (by > 65535) return fail(XM_ERR_INVALID_ARG, "baseline_als: n_batch too large for one launch (> 2M spectra)");
+  dim3 tgrid((n + 31) / 32, (unsigned)by), tblock(32, 8);
+  if (dtype == XM_C64) {
+    if (is_complex)
+      hipLaunchKernelGGL((k_als_transpose_in<float, true>), tgrid, tblock, 0, st, (const float*)in, (long long)n_batch, n, yt);
+    else
+      hipLaunchKernelGGL((k_als_transpose_in<float, false>), tgrid, tblock, 0, st, (const float*)in, (long long)n_batch, n, yt);
+  } else {
+    if (is_complex)
+      hipLaunchKernelGGL((k_als_transpose_in<double, true>), tgrid, tblock, 0, st, (const double*)in, (long long)n_batch, n, yt);
+    else
+      hipLaunchKernelGGL((k_als_transpose_in<double, false>), tgrid, tblock, 0, st, (const double*)in, (long long)n_batch, n, yt);
+  }
+  hipLaunchKernelGGL(k_als_solve, dim3((unsigned)((n_batch + 63) / 64)), dim3(64), 0, st, yt, zt, l1t, l2t, vt,
+                     (long long)n_batch, n, lam, p, n_iter);
+  hipLaunchKernelGGL(k_als_transpose_out, tgrid, tblock, 0, st, yt, zt, (long long)n_batch, n, (double*)out);
   HIP_TRY(hipGetLastError());
   return XM_OK;
 }

@@ -286,12 +286,19 @@ int xm_solver_set_threads(void* h, int threads) {
 
 int xm_solver_get_threads(void* h) { return ((Solver*)h)->threads; }
 
+// One search at a time owns the pool (two Python threads may call xm_solver_de concurrently).
+static std::mutex g_search_mu;
+
 void xm_solver_pool_begin(int threads) {
+  g_search_mu.lock();
   Pool& p = Pool::get();
   p.ensure(threads - 1);
   p.activate();
 }
 
-void xm_solver_pool_end(void) { Pool::get().park(); }
+void xm_solver_pool_end(void) {
+  Pool::get().park();
+  g_search_mu.unlock();
+}
 
 }  // extern "C"

@@ -201,6 +201,29 @@ def shift_fractional(x, axis: int, start: int, table):
     return restore(out)
 
 
+def baseline_als(x, axis: int, lam: float, p: float, n_iter: int):
+    """baseline.py:10-40 along `axis`: returns real(x) - AsLS baseline as float64 (any real or complex
+    float32/float64 input).  fp64 band LDL' solves, one thread per spectrum on transposed scratch."""
+    torch = _torch()
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise RuntimeError("xmris_amd has no CPU path: the tensor must live on a HIP device")
+    is_complex = x.is_complex()
+    if x.dtype in (torch.complex64, torch.float32):
+        code = _lib.XM_C64
+    elif x.dtype in (torch.complex128, torch.float64):
+        code = _lib.XM_C128
+    else:
+        raise TypeError(f"baseline_als needs float32/float64 (complex) data, got {x.dtype}")
+    x2, restore = _rows(x, axis)
+    nb, n = x2.shape
+    need = int(_lib.load().xm_baseline_als_workspace_bytes(nb, n))
+    work = torch.empty(max(need // 8, 1), dtype=torch.float64, device=x.device)
+    out = torch.empty((nb, n), dtype=torch.float64, device=x.device)
+    _lib.call("xm_baseline_als", x2.data_ptr(), int(is_complex), nb, n, float(lam), float(p), int(n_iter),
+              out.data_ptr(), work.data_ptr(), need, code, torch.cuda.current_stream(x.device).cuda_stream)
+    return restore(out)
+
+
 def absmax_argmax(x):
     """phasing.py:229 ``int(np.argmax(np.abs(values)))``: (max |x|, first flat C-order index).
 
