@@ -108,12 +108,14 @@ struct HotTw {  // middle stages from an LDS copy of the table, last stage from 
 
 // V = element real type: a scalar (one spectrum per NT threads) or a two-lane vector (two transforms
 // carried side by side in the packed-math lanes).
-template <class V, class PL>
+template <class V, class PL, int SH_OVERRIDE = -1>
 struct BlockFFT {
   using S = typename ScalarOf<V>::type;
   static constexpr int N = PL::N, NT = PL::NT, P = PL::P, K = PL::K;
-  static constexpr int SH = xm_pad_shift((int)sizeof(Cx<V>));
-  static constexpr int lds_elems() { return PL::lds_elems((int)sizeof(Cx<V>)); }
+  // pad shift: one pad element per 2^SH elements (default: per 128 bytes); a kernel that must squeeze
+  // two workgroups into the LDS may ask for sparser padding
+  static constexpr int SH = SH_OVERRIDE >= 0 ? SH_OVERRIDE : xm_pad_shift((int)sizeof(Cx<V>));
+  static constexpr int lds_elems() { return K > 1 ? (N + (N >> SH)) : 0; }
 
   template <int ST, int U, int R1, int R, class TW>
   XM_DEV static void twiddle_row(Cx<V>* a, const TW& tw, int k) {

@@ -273,8 +273,12 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
   constexpr unsigned N = 2 * PL::N, NT = PL::NT;
   constexpr int P = PL::P;
   constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
-  using V = typename PairOf<T>::type;  // lane x: even-bin half-FFT, lane y: odd-bin half-FFT
-  using FFT = BlockFFT<V, PL>;
+  // float: the two half-FFTs ride in the two lanes of the packed-f32 VALU (lane x: even bins, lane y:
+  // odd bins).  double: no packed f64 math exists, so the halves run one after the other through a
+  // 16-byte-element exchange buffer (padded every 16 elements so that two workgroups fit the LDS).
+  constexpr bool PACKED = sizeof(T) == 4;
+  using V = typename std::conditional<PACKED, typename PairOf<T>::type, T>::type;
+  using FFT = BlockFFT<V, PL, PACKED ? -1 : 4>;
   using HT = HotTw<T, PL>;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
@@ -323,13 +327,19 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     asm volatile("" : "+s"(nin));
     asm volatile("" : "+s"(pl));
     const unsigned toff2 = tt - pl;
-    Cx<V> v[P];
+    Cx<V> v[P];                   // packed: both halves; unpacked: the even-bin half
+    Cx<T> vo[PACKED ? 1 : P];     // unpacked: the odd-bin half
     static_for<0, P>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       const Cx<T> e = xr[q] * w[q];
       const Cx<T> o = mul_w<q, 2 * P, T>(e * rot);
-      v[q].re = V{e.re, o.re};
-      v[q].im = V{e.im, o.im};
+      if constexpr (PACKED) {
+        v[q].re = V{e.re, o.re};
+        v[q].im = V{e.im, o.im};
+      } else {
+        v[q] = e;
+        vo[q] = o;
+      }
     });
     const long long s2 = s + gridDim.x;
     if (s2 < A.n_batch) {  // prefetch the next FID while this one is transformed
@@ -339,22 +349,42 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     }
 
     FFT::run(v, lds, tw, (int)tt);
+    if constexpr (!PACKED) FFT::run(vo, lds, tw, (int)tt);
+    // (even, odd) outputs of butterfly q as scalars
+    auto even = [&](int q) -> Cx<T> {
+      if constexpr (PACKED) return mk<T>(v[q].re.x, v[q].im.x); else return v[q];
+    };
+    auto odd = [&](int q) -> Cx<T> {
+      if constexpr (PACKED) return mk<T>(v[q].re.y, v[q].im.y); else return vo[q];
+    };
 
     const unsigned t2 = 2u * tt;
     if constexpr (AMAX) {  // thread-local max |X|^2 first (packed), then the first index holding it
+      auto mag2 = [&](int q, T& me, T& mo) {
+        if constexpr (PACKED) {
+          const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
+          me = m2.x;
+          mo = m2.y;
+        } else {
+          me = v[q].re * v[q].re + v[q].im * v[q].im;
+          mo = vo[q].re * vo[q].re + vo[q].im * vo[q].im;
+        }
+      };
       T bv = T(-1);
 #pragma unroll
       for (int q = 0; q < P; ++q) {
-        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
-        bv = fmax(bv, fmax(m2.x, m2.y));
+        T me, mo;
+        mag2(q, me, mo);
+        bv = fmax(bv, fmax(me, mo));
       }
       int bi = 0x7fffffff;
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2);
-        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
-        bi = min(bi, m2.x == bv ? k0 : 0x7fffffff);
-        bi = min(bi, m2.y == bv ? k0 + 1 : 0x7fffffff);
+        T me, mo;
+        mag2(q, me, mo);
+        bi = min(bi, me == bv ? k0 : 0x7fffffff);
+        bi = min(bi, mo == bv ? k0 + 1 : 0x7fffffff);
       }
       amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
     }
@@ -364,8 +394,8 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
-        Cx<T> xe = mk<T>(v[q].re.x, v[q].im.x);
-        Cx<T> xo = mk<T>(v[q].re.y, v[q].im.y);
+        Cx<T> xe = even(q);
+        Cx<T> xo = odd(q);
         if constexpr (PHASE) {
           const CxPair<T> ph = buf_load(rph, t2 * CB, base * CB, (CxPair<T>*)nullptr);
           xe = xe * ph.a;
