@@ -1,0 +1,25 @@
+"""Main-pass timing of the BASELINE.json parity configs (C1, C2, C5) next to C3, c64."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xmris_amd import device as dev
+def run(name, nv, nt, N):
+    x = torch.view_as_complex(torch.randn(nv, nt, 2, device="cuda"))
+    w = torch.rand(N, device="cuda"); ph = torch.view_as_complex(torch.randn(N, 2, device="cuda"))
+    out = torch.empty(nv, N, dtype=torch.complex64, device="cuda")
+    am = torch.empty(nv, device="cuda"); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
+    for label, kw in (("pre ", dict(want_out=False, want_argmax=True)), ("main", dict(want_out=True, phase_table=ph))):
+        f = lambda: dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=am, argidx=ai, **kw)
+        for _ in range(3): f()
+        torch.cuda.synchronize(); ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts)); by = nv * 8 * (nt + (N if label == "main" else 0))
+        print(f"{name:34s} {label} {ms:8.4f} ms  {by/ms/1e6:8.1f} GB/s  {nv/ms/1e3:8.2f} M spectra/s")
+run("C1 5 x 1024 -> 2048", 5, 1024, 2048)
+run("C2 16384 x 2048 -> 4096", 16384, 2048, 4096)
+run("C2' 16384 x 2048 (no-op zero fill)", 16384, 2048, 2048)
+run("C3 65536 x 4096 -> 8192", 65536, 4096, 8192)
+run("C5 32768 x 1536", 32768, 1536, 1536)
+run("prime 32768 x 1531 (Bluestein)", 32768, 1531, 1531)
+run("65536 x 4096 (no zero fill)", 65536, 4096, 4096)

@@ -79,12 +79,15 @@ struct GlobalTw {  // every stage from the (L2-resident) global table
 };
 
 template <class S, class PL>
-struct HotTw {  // middle stages from an LDS copy of the table, last stage from per-thread registers
+struct HotTw {  // middle stages from an LDS copy of the table (or the global table when that copy would be
+                // larger than 8 KiB), last stage from per-thread registers
   static constexpr int K = PL::K;
   static constexpr int RL = PL::radix(K - 1);
   static constexpr int NREG = (K > 1) ? (PL::P / RL) * (RL - 1) : 1;
   static constexpr int mid_size() { return K > 1 ? PL::tw_offset(K - 1) : 0; }
-  const Cx<S>* mid;  // LDS, mid_size() entries
+  static constexpr bool mid_in_lds() { return mid_size() * (int)sizeof(Cx<S>) <= 8192; }
+  static constexpr int mid_lds_size() { return mid_in_lds() ? mid_size() : 0; }
+  const Cx<S>* mid;  // mid_size() entries: LDS copy or the global table itself
   Cx<S> reg[NREG];
   // thread t loads its last-stage twiddles: butterfly b = t + NT*u, input r -> table[(r-1)*Ns + b]
   XM_DEV void load(const Cx<S>* __restrict__ tw, int t) {

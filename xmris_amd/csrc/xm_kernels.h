@@ -411,6 +411,130 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
 }
 
 // =================================================================================================
+// Generic persistent kernel: TWO spectra ride in the two packed-f32 lanes (lane x: row 2g, lane y: row
+// 2g+1), same structure as k_zf2 (persistent workgroups, window / last-stage twiddles in registers,
+// middle-stage twiddles in LDS, next pair prefetched).  Any direct plan with NT >= 64 whose 16-byte
+// exchange buffer fits the LDS; rolls, inverse, window, phase and arg-max as in k_pipe.
+// =================================================================================================
+template <class PL>
+constexpr int fft2_waves() {
+  int w = PL::NT / 128;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
+template <class PL, int MODE>
+__global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<float> A) {
+  using T = float;
+  using V = xm_f2;
+  constexpr int N = PL::N, NT = PL::NT, P = PL::P;
+  constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  using FFT = BlockFFT<V, PL>;
+  using HT = HotTw<T, PL>;
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
+  Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
+  T* red_v = reinterpret_cast<T*>(mid + HT::mid_lds_size());
+  int* red_i = reinterpret_cast<int*>(red_v + 2 * (NT / XM_WAVE) + 2);
+  const int t = threadIdx.x;
+
+  HT tw;
+  tw.load(A.tw, t);
+  if constexpr (HT::mid_in_lds()) {
+    tw.mid = mid;
+    for (int i = t; i < HT::mid_size(); i += NT) mid[i] = A.tw[i];
+  } else {
+    tw.mid = A.tw;
+  }
+  // FFT input position pos = t + NT*q holds padded sample j = (pos - in_shift) mod N = input sample j - pad_left
+  T w[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    int j = t + NT * q - A.in_shift;
+    if (j < 0) j += N;
+    const bool ok = (unsigned)(j - A.pad_left) < (unsigned)A.n_in;
+    w[q] = ok ? (A.window ? A.window[j] * A.scale : A.scale) : T(0);
+  }
+  __syncthreads();
+
+  const long long npairs = (A.n_batch + 1) / 2;
+  const unsigned last_in = (unsigned)A.n_in - 1u;
+  Cx<T> x0[P], x1[P];
+  auto fetch = [&](long long g, int tt, int shift, int padl, unsigned lastv) {
+    const long long s0 = 2 * g, s1 = (2 * g + 1 < A.n_batch) ? 2 * g + 1 : 2 * g;  // odd tail: duplicate row
+    const Cx<T>* __restrict__ r0 = A.in + s0 * A.in_stride;
+    const Cx<T>* __restrict__ r1 = A.in + s1 * A.in_stride;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      int j = tt + NT * q - shift;
+      if (j < 0) j += N;
+      const unsigned src = min((unsigned)(j - padl), lastv);  // clamped; zero-filled positions have w = 0
+      x0[q] = r0[src];
+      x1[q] = r1[src];
+    }
+  };
+  long long g = blockIdx.x;
+  if (g < npairs) fetch(g, t, A.in_shift, A.pad_left, last_in);
+
+  for (; g < npairs; g += gridDim.x) {
+    int tt = t, osh = A.out_shift, ish = A.in_shift, padl = A.pad_left;
+    unsigned lastv = last_in;
+    asm volatile("" : "+v"(tt));  // keep per-lane address arithmetic inside the loop (see k_zf2)
+    asm volatile("" : "+s"(osh));
+    asm volatile("" : "+s"(ish));
+    asm volatile("" : "+s"(padl));
+    asm volatile("" : "+s"(lastv));
+    Cx<V> v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      v[q].re = V{x0[q].re, x1[q].re} * w[q];
+      v[q].im = V{x0[q].im, x1[q].im} * w[q];
+      if (A.inverse) v[q].im = -v[q].im;
+    }
+    if (g + gridDim.x < npairs) fetch(g + gridDim.x, tt, ish, padl, lastv);
+
+    FFT::run(v, lds, tw, tt);
+
+    const long long s0 = 2 * g, s1 = 2 * g + 1;
+    const bool has1 = s1 < A.n_batch;
+    if constexpr (AMAX) {
+      T b0 = T(-1), b1 = T(-1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
+        b0 = fmax(b0, m2.x);
+        b1 = fmax(b1, m2.y);
+      }
+      int i0 = 0x7fffffff, i1 = 0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        int k = tt + NT * q + osh;
+        if (k >= N) k -= N;
+        const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
+        i0 = min(i0, m2.x == b0 ? k : 0x7fffffff);
+        i1 = min(i1, m2.y == b1 ? k : 0x7fffffff);
+      }
+      amax_reduce_store<T, NT>(b0, i0, tt, true, s0, A.absmax2, A.argidx, red_v, red_i);
+      amax_reduce_store<T, NT>(b1, i1, tt, has1, has1 ? s1 : s0, A.absmax2, A.argidx, red_v + NT / XM_WAVE + 1,
+                               red_i + NT / XM_WAVE + 1);
+    }
+    if constexpr (WRITE) {
+      Cx<T>* __restrict__ o0 = A.out + s0 * (long long)N;
+      Cx<T>* __restrict__ o1 = A.out + (has1 ? s1 : s0) * (long long)N;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        int k = tt + NT * q + osh;
+        if (k >= N) k -= N;
+        Cx<V> y = v[q];
+        if (A.inverse) y.im = -y.im;
+        if constexpr (PHASE) y = y * A.phase[k];
+        o0[k] = mk<T>(y.re.x, y.im.x);
+        if (has1) o1[k] = mk<T>(y.re.y, y.im.y);
+      }
+    }
+  }
+}
+
+// =================================================================================================
 // Bluestein (chirp-z) kernel for lengths without a direct plan.  PL = power-of-two plan of
 // length M >= 2n-1.   X[m] = a[m] * sum_k (z[k] a[k]) b[m-k],  a[k] = e^{-i pi k^2/n}, b = conj(a).
 // aux = a (n entries), aux2 = FFT_M(b wrapped) / M (M entries), both fp64-computed on the host.

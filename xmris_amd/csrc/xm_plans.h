@@ -26,6 +26,10 @@
   X(2048, 256, 8, 8, 8, 4)    \
   X(4096, 512, 8, 8, 8, 8)
 
+// plans of the generic persistent kernel (k_fft2, complex64): power-of-two lengths reuse the 8-point
+// shapes above (two spectra per lane pair double the per-thread state), plus 8192
+#define XM_PLANS_FFT2_EXTRA(X) X(8192, 1024, 8, 8, 8, 8, 2)
+
 // tiny lengths and 3*2^k / 5*2^k lengths: generic kernel only
 #define XM_PLANS_OTHER(X)     \
   X(2, 1, 2)                  \
@@ -64,4 +68,5 @@ struct Zf2PlanOf;
     using type = FftPlan<N, NT, __VA_ARGS__>; \
   };
 XM_PLANS_ZF2(XM_DEF_PLAN)
+XM_PLANS_FFT2_EXTRA(XM_DEF_PLAN)
 #undef XM_DEF_PLAN
