@@ -63,8 +63,8 @@ def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--voxels", type=int, default=65536, help="voxels per GPU")
     ap.add_argument("--n-time", type=int, default=4096)
     ap.add_argument("--target-points", type=int, default=8192)
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not queue the next step's pre-pass while the host solves the current one")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl",
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --share-gpu) to exercise "
                          "the multi-rank code path on a single-GPU box; the driver uses the default (RCCL)")
@@ -268,35 +268,41 @@ def main():
 
 
 def cpu_baseline(x, t, N, lb, budget_s, nv_full):
-    """The CPU oracle (numpy/scipy restatement, complex128 like the reference, 1 core) on a bounded
-    sample of the same workload: the first `m` voxels, streaming stages timed on the sample and the
-    O(1) DE solve timed once; the reported rate is the projection to the full voxel count."""
+    """The CPU oracle (numpy/scipy restatement issuing the reference's library calls, complex128 like the
+    reference, ONE core) on a bounded sample of the same workload: chunks of 2048 voxels are processed until
+    ~budget_s seconds of CPU work have been spent.  Per chunk: pad -> window -> ortho FFT -> roll -> |X|
+    arg-max (timed) and the broadcast phase multiply (timed, with the final table's cost); the O(1)
+    differential-evolution solve on the best slice is timed once.  value = projection to the full voxel
+    count: nv / (nv * per_spectrum + DE)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xmris_oracle as orc
 
-    probe = x[:32].cpu().numpy().astype(np.complex128)
-    t0 = time.perf_counter()
-    orc.pipeline_values(probe, t, N, lb, solve=False)
-    per = (time.perf_counter() - t0) / 32
-    m = int(max(64, min(4096, budget_s * 0.6 / max(per, 1e-9))))
-    m = min(m, x.shape[0])
-    sample = x[:m].cpu().numpy().astype(np.complex128)
-    t0 = time.perf_counter()
-    spec, info = orc.pipeline_values(sample, t, N, lb, solve=False)
-    t_stream_a = time.perf_counter() - t0
+    chunk, done, t_stream = 2048, 0, 0.0
+    best = (-1.0, None, None)
+    info = None
+    while done < x.shape[0] and t_stream < budget_s:
+        xs = x[done:done + chunk].cpu().numpy().astype(np.complex128)
+        t0 = time.perf_counter()
+        spec, inf = orc.pipeline_values(xs, t, N, lb, solve=False)
+        amax = float(np.abs(inf["slice"]).max())
+        t1 = time.perf_counter()
+        dummy = orc.phase_values(spec, inf["freq"], 1, 10.0, 20.0, inf["pivot"])  # same cost as the final multiply
+        t2 = time.perf_counter()
+        del dummy, spec
+        t_stream += t2 - t0
+        done += xs.shape[0]
+        if amax > best[0]:
+            best, info = (amax, inf["slice"], inf["target_idx"]), inf
     t0 = time.perf_counter()
     p0, p1, opt = orc.autophase_solve(info["slice"], info["freq"], info["pivot"], info["target_idx"], 1)
     t_de = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.phase_values(spec, info["freq"], 1, p0, p1, info["pivot"])
-    t_stream_b = time.perf_counter() - t0
-    per_spec = (t_stream_a + t_stream_b) / m
+    per_spec = t_stream / done
     full = nv_full * per_spec + t_de
     return {
         "value": nv_full / full, "unit": "spectra/s", "cores": 1, "kind": "port",
-        "sample": f"oracle (numpy {np.__version__} pocketfft + scipy DE, complex128) on the first {m} voxels: "
-                  f"streaming {per_spec * 1e3:.3f} ms/spectrum, DE solve {t_de:.3f} s once per dataset "
-                  f"({int(opt.nfev)} evals); value = {nv_full} / ({nv_full} x per-spectrum + DE)",
+        "sample": f"oracle (numpy {np.__version__} pocketfft + scipy DE, complex128) on the first {done} of {nv_full} voxels "
+                  f"({t_stream:.1f} s of streaming work): {per_spec * 1e3:.3f} ms/spectrum, DE solve {t_de:.3f} s once per "
+                  f"dataset ({int(opt.nfev)} evals); value = {nv_full} / ({nv_full} x per-spectrum + DE)",
         "streaming_spectra_per_s": 1.0 / per_spec, "de_solve_s": t_de, "host_cpus": os.cpu_count(),
     }
 
