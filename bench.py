@@ -140,10 +140,10 @@ def main():
         b = i & 1
         ev["pre0"][i].record()
         dev.pipeline_fused(x, N, 0, window=plan.window, want_out=False, want_argmax=True, absmax2=absmax2[b],
-                           argidx=argidx[b])
+                           argidx=argidx[b], argmax_value_only=True)
         ev["pre1"][i].record()
         # selection stage queued right behind it (device-side arg-max -> fp64 slice -> pinned host copies)
-        sel[b] = pipeline.Selection(x, plan, absmax2[b], argidx[b])
+        sel[b] = pipeline.Selection(x, plan, absmax2[b], argidx[b], index_from_slice=True)
 
     def run_steps(n_steps, record):
         """n_steps complete passes of the hot path.  Datasets are independent, so with `overlap` the

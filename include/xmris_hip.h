@@ -43,6 +43,8 @@ typedef enum {
 #define XM_FFT_ORTHO 2u     /* scale 1/sqrt(N)   (norm="ortho", fourier.py:153)             */
 #define XM_FFT_SHIFT_IN 4u  /* roll the INPUT by (N+1)/2 first  (ifftshift, fourier.py:57)  */
 #define XM_FFT_SHIFT_OUT 8u /* roll the OUTPUT by N/2 afterwards (fftshift, fourier.py:31)  */
+#define XM_AMAX_VALUE_ONLY 16u /* xm_pipeline_fused: absmax2[b] only, argidx[b] is written as 0 (the caller
+                                  recovers the index along the axis from the winning spectrum itself)      */
 
 int xm_version(void); /* 10000*major + 100*minor + patch */
 const char* xm_last_error_string(void);

@@ -20,6 +20,11 @@ are closed-form numpy expressions held in the hidden assert cells of
 NOT pinned by any reference test: the numerical value of autophase's (p0, p1)
 (the only such assertion is commented out in `pipeline/autophasing.md:158-162`).
 
+Also restated (SURVEY.md section 8f "next" rows built in round 1): ``remove_digital_filter``
+(`vendor/bruker.py:7-118`) and ``baseline_als`` (`processing/baseline.py:10-119`), pinned by the
+known-answer cells of `vendor/bruker_filter_removal.md` and `pipeline/baseline.md`
+(`tests/test_bruker_filter.py`, `tests/test_baseline_als.py`).
+
 Data model
 ----------
 xarray is not installed here, so the oracle works on a tiny labelled-array record

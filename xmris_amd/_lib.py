@@ -17,6 +17,7 @@ XM_FFT_INVERSE = 1
 XM_FFT_ORTHO = 2
 XM_FFT_SHIFT_IN = 4
 XM_FFT_SHIFT_OUT = 8
+XM_AMAX_VALUE_ONLY = 16
 
 XM_ERR_INVALID_ARG = -1
 XM_ERR_UNSUPPORTED_N = -2

@@ -343,7 +343,7 @@ int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const vo
     return fail(XM_ERR_INVALID_ARG, "pipeline: absmax2 and argidx must be given together");
   if (!out && !absmax2) return fail(XM_ERR_INVALID_ARG, "pipeline: nothing to produce");
   if (out == in) return fail(XM_ERR_INVALID_ARG, "pipeline: in-place operation is not supported");
-  if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT))
+  if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT | XM_AMAX_VALUE_ONLY))
     return fail(XM_ERR_INVALID_ARG, "pipeline: unknown flag bits");
   if (!xm_supported(n_out, dtype))
     return fail(XM_ERR_UNSUPPORTED_N, "no in-LDS plan for length " + std::to_string(n_out));

@@ -27,6 +27,7 @@ struct PipeArgs {
   int n;                  // transform length (n_out)
   int n_in, pad_left, in_shift, out_shift;
   int inverse;
+  int amax_value_only;    // skip the first-index scan (argidx written as 0)
   T scale;
 };
 
@@ -377,14 +378,17 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         mag2(q, me, mo);
         bv = fmax(bv, fmax(me, mo));
       }
-      int bi = 0x7fffffff;
+      int bi = 0;
+      if (!A.amax_value_only) {  // wave-uniform
+        bi = 0x7fffffff;
 #pragma unroll
-      for (int q = 0; q < P; ++q) {
-        const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2);
-        T me, mo;
-        mag2(q, me, mo);
-        bi = min(bi, me == bv ? k0 : 0x7fffffff);
-        bi = min(bi, mo == bv ? k0 + 1 : 0x7fffffff);
+        for (int q = 0; q < P; ++q) {
+          const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2);
+          T me, mo;
+          mag2(q, me, mo);
+          bi = min(bi, me == bv ? k0 : 0x7fffffff);
+          bi = min(bi, mo == bv ? k0 + 1 : 0x7fffffff);
+        }
       }
       amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
     }

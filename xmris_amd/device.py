@@ -259,7 +259,7 @@ class FusedResult:
 
 def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
                    ortho: bool = True, want_out: bool = True, want_argmax: bool = False, out=None,
-                   absmax2=None, argidx=None):
+                   absmax2=None, argidx=None, argmax_value_only: bool = False):
     """One launch of zero-fill + window + FFT(+fftshift) [+ |X|^2 arg-max] [+ phase] on
     ``x2`` = [n_batch, n_in] contiguous rows (FID axis last).  `window` / `phase_table` are
     device tensors of the storage precision (real n_out / complex n_out) or None."""
@@ -277,6 +277,8 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
         if argidx is None:
             argidx = torch.empty(nb, dtype=torch.int32, device=x2.device)
     flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    if argmax_value_only:  # hint: kernels may skip the first-index scan (argidx then holds 0)
+        flags |= _lib.XM_AMAX_VALUE_ONLY
     _lib.call(
         "xm_pipeline_fused", x2.data_ptr(), n_in, out.data_ptr() if want_out else None,
         window.data_ptr() if window is not None else None,

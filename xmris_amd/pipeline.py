@@ -90,10 +90,11 @@ class Selection:
     pinned host memory, closed by an event.  `wait()` blocks on that event only, so kernels queued
     later on the same stream (another dataset's main pass) do not delay the host solver."""
 
-    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx):
+    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False):
         import torch
 
         n = plan.n_out
+        self.index_from_slice = index_from_slice  # pre-pass ran with argmax_value_only: only the ROW is known
         if plan.window64 is None:
             plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
         self.n = n
@@ -118,7 +119,11 @@ class Selection:
 
     def wait(self):
         self.event.synchronize()
-        return float(self.h_max.item()) ** 0.5, int(self.h_flat.item()), self.h_slice.numpy().copy()
+        sl = self.h_slice.numpy().copy()
+        flat = int(self.h_flat.item())
+        if self.index_from_slice:  # index along the axis = first arg-max of the (fp64) winning spectrum
+            flat = (flat // self.n) * self.n + int(np.argmax(np.abs(sl)))
+        return float(self.h_max.item()) ** 0.5, flat, sl
 
 
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
@@ -183,9 +188,12 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     if plan is None:
         plan = make_plan(x2, t, target_points, lb)
     n = plan.n_out
-    pre = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True)
+    # with a solve, only the winning ROW is needed from the pre-pass (its index along the axis comes from
+    # the winning spectrum itself, recomputed in fp64); injected parameters need the full arg-max
+    pre = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True,
+                             argmax_value_only=params is None)
     if params is None:  # arg-max reduction, row gather, fp64 slice and D2H all queued without host syncs
-        sel = Selection(x2, plan, pre.absmax2, pre.argidx)
+        sel = Selection(x2, plan, pre.absmax2, pre.argidx, index_from_slice=True)
         res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only,
                                   selection=sel)
     else:
