@@ -115,9 +115,22 @@ template <class V, class PL, int SH_OVERRIDE = -1>
 struct BlockFFT {
   using S = typename ScalarOf<V>::type;
   static constexpr int N = PL::N, NT = PL::NT, P = PL::P, K = PL::K;
-  // pad shift: one pad element per 2^SH elements (default: per 128 bytes); a kernel that must squeeze
-  // two workgroups into the LDS may ask for sparser padding
-  static constexpr int SH = SH_OVERRIDE >= 0 ? SH_OVERRIDE : xm_pad_shift((int)sizeof(Cx<V>));
+  // pad shift: one pad element per 2^SH elements.  Default: per 128 bytes.  For 16-byte elements and a
+  // power-of-two first radix R0 >= 8 the stage-0 scatter (lane stride R0 elements) wants exactly one pad per
+  // R0 elements: the lane stride becomes R0*16+16 bytes = 4 dwords (mod 32 banks), i.e. the 8 lanes of a
+  // ds_write_b128 group land on 8 distinct 4-bank slots (R0 = 16 with a pad every 8 elements was a 2-way
+  // conflict: 37 % of the LDS cycles of the 16-point plan).  A kernel that must squeeze two workgroups
+  // into the LDS may override.
+  static constexpr int r0_shift() {
+    const int r0 = PL::radix(0);
+    if (sizeof(Cx<V>) >= 16 && r0 >= 8 && (r0 & (r0 - 1)) == 0) {
+      int s = 0;
+      while ((1 << s) < r0) ++s;
+      return s;
+    }
+    return xm_pad_shift((int)sizeof(Cx<V>));
+  }
+  static constexpr int SH = SH_OVERRIDE >= 0 ? SH_OVERRIDE : r0_shift();
   static constexpr int lds_elems() { return K > 1 ? (N + (N >> SH)) : 0; }
 
   template <int ST, int U, int R1, int R, class TW>
