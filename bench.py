@@ -102,6 +102,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node: the container hostname may not resolve
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # RCCL: barrier / timing reductions
         else:
