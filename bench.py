@@ -262,6 +262,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, t, N, args.lb, args.cpu_seconds, nv)
+        result["cpu_baseline_all_cores"] = cpu_baseline_threads(x, t, N, args.lb, nv,
+                                                                result["cpu_baseline"]["de_solve_s"])
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -305,6 +307,36 @@ def cpu_baseline(x, t, N, lb, budget_s, nv_full):
                   f"({t_stream:.1f} s of streaming work): {per_spec * 1e3:.3f} ms/spectrum, DE solve {t_de:.3f} s once per "
                   f"dataset ({int(opt.nfev)} evals); value = {nv_full} / ({nv_full} x per-spectrum + DE)",
         "streaming_spectra_per_s": 1.0 / per_spec, "de_solve_s": t_de, "host_cpus": os.cpu_count(),
+    }
+
+
+def cpu_baseline_threads(x, t, N, lb, nv_full, t_de, n_sample=16384, chunk=64):
+    """the same oracle calls with the voxel axis sharded over the host's cores (numpy's
+    pocketfft and ufuncs release the GIL, so a thread pool scales; no fork/exec after the GPU is initialised).
+    Wall time of the streaming stages on `n_sample` voxels, projected to the full count, plus the one DE solve."""
+    from concurrent.futures import ThreadPoolExecutor
+    import xmris_oracle as orc
+
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    n_sample = min(n_sample, x.shape[0])
+    xs = x[:n_sample].cpu().numpy().astype(np.complex128)
+
+    def work(lo):
+        spec, inf = orc.pipeline_values(xs[lo:lo + chunk], t, N, lb, solve=False)
+        amax = float(np.abs(inf["slice"]).max())
+        orc.phase_values(spec, inf["freq"], 1, 10.0, 20.0, inf["pivot"])
+        return amax
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(0, n_sample, chunk)))
+    wall = time.perf_counter() - t0
+    per_spec = wall / n_sample
+    return {
+        "value": nv_full / (nv_full * per_spec + t_de), "unit": "spectra/s", "cores": cores, "kind": "port",
+        "sample": f"oracle sharded over {cores} threads in chunks of {chunk} voxels, first {n_sample} of {nv_full} voxels "
+                  f"in {wall:.2f} s wall; DE solve {t_de:.3f} s once per dataset (single-threaded scipy)",
+        "streaming_spectra_per_s": 1.0 / per_spec,
     }
 
 

@@ -128,6 +128,11 @@ void* xm_solver_create(const double* slice_re_im, const double* coords, int n, d
 void xm_solver_destroy(void* solver);
 /* objective value at x = (p0[, p1]) in degrees */
 double xm_solver_score(void* solver, const double* x, int nx);
+/* `count` parameter vectors, stored 2 doubles apart (p0[, p1] in degrees), evaluated in one hand-off to the worker
+ * team -> out[count]; each value equals xm_solver_score's for the same vector */
+void xm_solver_score_batch(void* solver, const double* xs, int nx, int count, double* out);
+/* objective evaluations performed so far (xm_solver_de evaluates some trials speculatively, so this can exceed the
+ * nfev it reports, which counts the evaluations of the sequential algorithm) */
 long xm_solver_nfev(void* solver);
 /* team size of one objective evaluation inside xm_solver_de (<= 0: min(16, hardware threads / 2); 1 = serial);
  * returns the value set.  Outside xm_solver_de evaluations are always serial. */

@@ -101,6 +101,19 @@ class NativeObjective:
     def set_threads(self, n):
         return self._lib.xm_solver_set_threads(self._h, int(n))
 
+    def evaluations(self):
+        """Objective evaluations performed so far (>= the sequential algorithm's nfev: xm_solver_de
+        evaluates trials speculatively in batches)."""
+        return int(self._lib.xm_solver_nfev(self._h))
+
+    def score_batch(self, xs):
+        xs = np.asarray(xs, dtype=np.float64)
+        buf = np.zeros((xs.shape[0], 2))
+        buf[:, :xs.shape[1]] = xs
+        out = np.empty(xs.shape[0])
+        self._lib.xm_solver_score_batch(self._h, buf.ctypes.data, int(xs.shape[1]), int(xs.shape[0]), out.ctypes.data)
+        return out
+
     def de(self, p0_only, seed=42, tol=0.01, maxiter=1000):
         import ctypes
 

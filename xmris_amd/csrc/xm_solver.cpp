@@ -102,7 +102,9 @@ double np_sum_small(const double* a, int n) {
 extern "C" {
 
 double xm_solver_score(void* h, const double* x, int nx);
+void xm_solver_score_batch(void* h, const double* xs, int nx, int count, double* out);
 int xm_solver_get_threads(void* h);
+int xm_solver_get_batch(void* h);
 void xm_solver_pool_begin(int threads);
 void xm_solver_pool_end(void);
 
@@ -148,66 +150,105 @@ int xm_solver_de(void* h, int p0_only, unsigned seed, double tol, int maxiter, d
   std::vector<int> ridx(M);
   for (int i = 0; i < M; ++i) ridx[i] = i;
   int nfev = 0;
-  double par[2], trial[2], bprime[2];
-  for (int i = 0; i < M; ++i) {
-    scale(&pop[i * N], par);
-    en[i] = xm_solver_score(h, par, N);
-    ++nfev;
+  double par[2];
+  {  // initial energies: M independent evaluations, one batch
+    std::vector<double> ps(2 * M, 0.0);
+    for (int i = 0; i < M; ++i) scale(&pop[i * N], &ps[2 * i]);
+    xm_solver_score_batch(h, ps.data(), N, M, en.data());
+    nfev += M;
   }
-  auto promote = [&]() {  // _promote_lowest_energy: first arg-min to slot 0
+  auto promote = [&]() {  // _promote_lowest_energy: first arg-min to slot 0; returns the slot it came from
     int l = 0;
     for (int i = 1; i < M; ++i)
       if (en[i] < en[l]) l = i;
     std::swap(en[0], en[l]);
     for (int j = 0; j < N; ++j) std::swap(pop[j], pop[l * N + j]);
+    return l;
   };
   promote();
+
+  // scipy walks the candidates one by one ("immediate" updating): trial c is built from the population as
+  // it stands after candidates < c were decided.  One evaluation is far shorter than a thread hand-off, so
+  // the next `batch` trials are built SPECULATIVELY from the current population, evaluated together
+  // (xm_solver_score_batch: one hand-off for the lot), and committed in order.  A trial reads only
+  // pop[c], pop[0] (the best), pop[r0], pop[r1] and the random stream, so it is exactly the trial scipy would
+  // build unless one of those four members changed earlier in the same batch; at the first such trial the
+  // rest of the batch is thrown away, the generator and the index array are rewound to their state before
+  // that trial, and speculation restarts there.  The sequence of accepted trials, energies and random
+  // draws is therefore identical to the sequential algorithm's.
+  struct Spec {
+    double trial[2];
+    int r0, r1;
+    MT19937 rng_before;
+    int ridx_before[30];
+  };
+  const int batch_max = std::max(1, std::min(M, xm_solver_get_batch(h)));
+  std::vector<Spec> spec(batch_max);
+  std::vector<double> ps(2 * batch_max, 0.0), es(batch_max);
+  std::vector<char> mod(M);
+  int batch = batch_max;
 
   int nit = 0, status = 1;
   std::vector<double> dev(M);
   for (nit = 1; nit <= maxiter; ++nit) {
     const double scl = 0.5 + (1.0 - 0.5) * rng.next_double();  // dither: rng.uniform(0.5, 1)
-    for (int c = 0; c < M; ++c) {
-      // _mutate
-      int fill_point = 0;
-      if (N > 1) {  // rng_integers(rng, N) -> randint(0, N): masked rejection on one 32-bit draw
-        uint32_t v;
-        const uint32_t rngv = (uint32_t)(N - 1);
-        uint32_t mask = rngv;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        while ((v = (rng.next32() & mask)) > rngv) {
+    for (int c = 0; c < M;) {
+      const int B = std::min(batch, M - c);
+      for (int b = 0; b < B; ++b) {
+        Spec& sp = spec[b];
+        const int cand = c + b;
+        sp.rng_before = rng;
+        std::memcpy(sp.ridx_before, ridx.data(), sizeof(int) * M);
+        // _mutate
+        int fill_point = 0;
+        if (N > 1) fill_point = (int)rng.interval((uint32_t)(N - 1));  // rng_integers(rng, N) -> randint(0, N)
+        rng.shuffle(ridx.data(), M);  // _select_samples(candidate, 5)
+        int smp[5], ns = 0;
+        for (int i = 0; i < 6 && ns < 5; ++i)
+          if (ridx[i] != cand) smp[ns++] = ridx[i];
+        sp.r0 = smp[0];
+        sp.r1 = smp[1];
+        double bprime[2];
+        for (int j = 0; j < N; ++j) {
+          sp.trial[j] = pop[cand * N + j];
+          bprime[j] = pop[j] + scl * (pop[sp.r0 * N + j] - pop[sp.r1 * N + j]);  // _best1
         }
-        fill_point = (int)v;
+        bool cross[2];
+        for (int j = 0; j < N; ++j) cross[j] = rng.next_double() < 0.7;
+        cross[fill_point] = true;
+        for (int j = 0; j < N; ++j)
+          if (cross[j]) sp.trial[j] = bprime[j];
+        // _ensure_constraint
+        for (int j = 0; j < N; ++j)
+          if (sp.trial[j] > 1 || sp.trial[j] < 0) sp.trial[j] = rng.next_double();
+        scale(sp.trial, &ps[2 * b]);
       }
-      rng.shuffle(ridx.data(), M);  // _select_samples(candidate, 5)
-      int smp[5], ns = 0;
-      for (int i = 0; i < 6 && ns < 5; ++i)
-        if (ridx[i] != c) smp[ns++] = ridx[i];
-      const int r0 = smp[0], r1 = smp[1];
-      for (int j = 0; j < N; ++j) {
-        trial[j] = pop[c * N + j];
-        bprime[j] = pop[j] + scl * (pop[r0 * N + j] - pop[r1 * N + j]);  // _best1
+      xm_solver_score_batch(h, ps.data(), N, B, es.data());
+      std::fill(mod.begin(), mod.end(), 0);
+      int b = 0;
+      for (; b < B; ++b) {
+        const Spec& sp = spec[b];
+        const int cand = c + b;
+        if (b > 0 && (mod[cand] | mod[0] | mod[sp.r0] | mod[sp.r1])) break;  // stale: rebuild from here
+        ++nfev;
+        if (es[b] <= en[cand]) {
+          for (int j = 0; j < N; ++j) pop[cand * N + j] = sp.trial[j];
+          en[cand] = es[b];
+          mod[cand] = 1;
+          if (es[b] <= en[0]) {
+            mod[promote()] = 1;
+            mod[0] = 1;
+          }
+        }
       }
-      bool cross[2];
-      for (int j = 0; j < N; ++j) cross[j] = rng.next_double() < 0.7;
-      cross[fill_point] = true;
-      for (int j = 0; j < N; ++j)
-        if (cross[j]) trial[j] = bprime[j];
-      // _ensure_constraint
-      for (int j = 0; j < N; ++j)
-        if (trial[j] > 1 || trial[j] < 0) trial[j] = rng.next_double();
-      scale(trial, par);
-      const double e = xm_solver_score(h, par, N);
-      ++nfev;
-      if (e <= en[c]) {
-        for (int j = 0; j < N; ++j) pop[c * N + j] = trial[j];
-        en[c] = e;
-        if (e <= en[0]) promote();
+      if (b < B) {  // rewind the random stream to just before the first stale trial
+        rng = spec[b].rng_before;
+        std::memcpy(ridx.data(), spec[b].ridx_before, sizeof(int) * M);
+        batch = std::max(std::min(4, batch_max), std::min(batch, 2 * b));
+      } else {
+        batch = std::min(batch_max, batch * 2);
       }
+      c += b;
     }
     // converged(): std(energies) <= atol + tol * |mean(energies)|
     bool any_inf = false;

@@ -8,6 +8,9 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -15,34 +18,96 @@
 
 namespace {
 
+// ln x for finite x > 0 (fdlibm's reduction x = 2^k (1 + f), sqrt(1/2) <= 1 + f < sqrt(2), and its degree-14
+// polynomial): branch-free and table-free, so the loop around it vectorises without gathers.  Absolute
+// error ~1e-16 on the reduced range; 0 maps to a finite value (the caller multiplies by x).
+static inline double fast_log(double x) {
+  int64_t ix;
+  std::memcpy(&ix, &x, 8);
+  const int64_t k = (ix - 0x3fe6a09e667f3bcdLL) >> 52;
+  const int64_t im = ix - (k << 52);
+  double m;
+  std::memcpy(&m, &im, 8);
+  const int64_t kb = k + 0x4338000000000000LL;  // double(k) = bits(k + 2^52 + 2^51) - (2^52 + 2^51)
+  double kd;
+  std::memcpy(&kd, &kb, 8);
+  kd -= 6755399441055744.0;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 +
+                         w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  return kd * 6.93147180559945286227e-01 + (f - s * (f - (t2 + t1)));
+}
+
 // One 256-sample chunk of the ACME objective.  Built twice (function multi-versioning): AVX-512 for
-// CPUs that have it (8-wide libmvec sin/cos/log), AVX2 otherwise; the dispatcher picks at load time.
+// CPUs that have it (8-wide libmvec sin/cos), AVX2 otherwise; the dispatcher picks at load time.
+// `uniform` says the coordinate is uniformly spaced (u[k] = u[0] + k du to rounding, the fftfreq axis the
+// path produces): e^{i phi} is then evaluated exactly only at every 16th sample and rotated by the 16
+// precomputed e^{i j p1 du} inside each block (one complex multiply instead of a sin and a cos per sample;
+// the rounding error stays at a few ulp because every block restarts from an exact anchor).
 __attribute__((target_clones("avx512f", "default"))) void acme_chunk_kernel(
     const double* __restrict__ re, const double* __restrict__ im, const double* __restrict__ u, int nn, int c0,
-    double p0r, double p1r, double* __restrict__ pc) {
+    double p0r, double p1r, double du, bool uniform, double* __restrict__ pc) {
   const int c1 = std::min(nn, c0 + 256);
-  double d[257], cs[257], sn[257];
+  alignas(64) double d[272];
   const int m = std::min(nn, c1 + 1) - c0;  // one extra sample for the forward difference
-  // separate loops so that gcc uses the libmvec vector cos / sin (a fused sincos call stays scalar)
+  if (uniform) {
+    alignas(64) double ang[32], cc[32], ss[32];
+    for (int b = 0; b < 16; ++b) ang[b] = p0r + p1r * u[std::min(c0 + 16 * b, nn - 1)];  // block anchors
+    for (int j = 0; j < 16; ++j) ang[16 + j] = p1r * du * (double)j;                      // in-block rotations
 #pragma omp simd
-  for (int k = 0; k < m; ++k) cs[k] = std::cos(p0r + p1r * u[c0 + k]);
+    for (int i = 0; i < 32; ++i) cc[i] = std::cos(ang[i]);
 #pragma omp simd
-  for (int k = 0; k < m; ++k) sn[k] = std::sin(p0r + p1r * u[c0 + k]);
+    for (int i = 0; i < 32; ++i) ss[i] = std::sin(ang[i]);
+    const double* rc = cc + 16;
+    const double* rs = ss + 16;
+    if (c0 + 256 <= nn) {
+      for (int b = 0; b < 16; ++b) {
+        const double ca = cc[b], sa = ss[b];
 #pragma omp simd
-  for (int k = 0; k < m; ++k) d[k] = re[c0 + k] * cs[k] - im[c0 + k] * sn[k];
+        for (int j = 0; j < 16; ++j) {
+          const int k = c0 + 16 * b + j;
+          d[16 * b + j] = re[k] * (ca * rc[j] - sa * rs[j]) - im[k] * (sa * rc[j] + ca * rs[j]);
+        }
+      }
+      if (m > 256) {  // sample 256 = anchor 15 advanced by 16 steps (rotation 15, then rotation 1)
+        const double c16 = rc[15] * rc[1] - rs[15] * rs[1], s16 = rs[15] * rc[1] + rc[15] * rs[1];
+        d[256] = re[c0 + 256] * (cc[15] * c16 - ss[15] * s16) - im[c0 + 256] * (ss[15] * c16 + cc[15] * s16);
+      }
+    } else {
+      for (int k = 0; k < m; ++k) {
+        const int b = k >> 4, j = k & 15;
+        d[k] = re[c0 + k] * (cc[b] * rc[j] - ss[b] * rs[j]) - im[c0 + k] * (ss[b] * rc[j] + cc[b] * rs[j]);
+      }
+    }
+  } else {
+    alignas(64) double cs[272], sn[272];
+    // separate loops so that gcc uses the libmvec vector cos / sin (a fused sincos call stays scalar)
+#pragma omp simd
+    for (int k = 0; k < m; ++k) cs[k] = std::cos(p0r + p1r * u[c0 + k]);
+#pragma omp simd
+    for (int k = 0; k < m; ++k) sn[k] = std::sin(p0r + p1r * u[c0 + k]);
+#pragma omp simd
+    for (int k = 0; k < m; ++k) d[k] = re[c0 + k] * cs[k] - im[c0 + k] * sn[k];
+  }
   double a_ds = 0, a_dl = 0, a_as = 0, a_as2 = 0, a_mx = -DBL_MAX;
-#pragma omp simd reduction(+ : a_ds, a_dl, a_as, a_as2) reduction(max : a_mx)
-  for (int k = 0; k < c1 - c0; ++k) {
+  const int nk = c1 - c0, nd = std::min(nk, nn - 1 - c0);  // the very last sample has no forward difference
+#pragma omp simd reduction(+ : a_as, a_as2) reduction(max : a_mx)
+  for (int k = 0; k < nk; ++k) {
     const double v = d[k];
     const double as_ = v - std::fabs(v);
     a_as += as_;
     a_as2 += (0.5 * as_) * (0.5 * as_);
     a_mx = std::max(a_mx, v);
-    if (c0 + k + 1 < nn) {
-      const double ds = std::fabs((d[k + 1] - v) * 0.5);
-      a_ds += ds;
-      a_dl += ds > 0 ? ds * std::log(ds) : 0.0;
-    }
+  }
+#pragma omp simd reduction(+ : a_ds, a_dl)
+  for (int k = 0; k < nd; ++k) {
+    const double ds = std::fabs((d[k + 1] - d[k]) * 0.5);
+    a_ds += ds;
+    a_dl += ds * fast_log(ds);  // ds == 0 contributes 0 (fast_log(0) is finite), as the reference's zeros -> 1 rule
   }
   pc[0] = a_ds;
   pc[1] = a_dl;
@@ -54,9 +119,12 @@ __attribute__((target_clones("avx512f", "default"))) void acme_chunk_kernel(
 struct Solver {
   int n = 0, method = 0, target_idx = 0, index_width = 1;
   double pivot = 0, x_range = 0;
+  double du = 0;         // spacing of u when `uniform`
+  bool uniform = false;  // u[k] == u[0] + k du to a few ulp (checked in xm_solver_create)
   std::vector<double> re, im, u;  // u[k] = (c[k] - pivot) / (max c - min c)   (phasing.py:69)
   long nfev = 0;
-  int threads = 1;  // OpenMP team for one objective evaluation (1 = serial)
+  int threads = 1;  // team size for objective evaluations (1 = serial)
+  int batch = 4;    // most trials xm_solver_de evaluates speculatively in one hand-off (measured optimum, 16 threads)
 
   // Re(slice[k] * e^{i phi_k}),  phi_k = rad(p0) + rad(p1) * u[k]        (phasing.py:62-73)
   inline double phased_real(int k, double p0r, double p1r) const {
@@ -66,10 +134,50 @@ struct Solver {
 
   // partial sums of one 256-sample chunk: {sum ds, sum ds*ln ds, sum a, sum (a/2)^2, max d}
   void acme_chunk(int c0, double p0r, double p1r, double* pc) const {
-    acme_chunk_kernel(re.data(), im.data(), u.data(), n, c0, p0r, p1r, pc);
+    acme_chunk_kernel(re.data(), im.data(), u.data(), n, c0, p0r, p1r, du, uniform, pc);
+  }
+  // A "part" = kPartChunks consecutive chunks (2048 samples), the unit of work handed to a team member; its
+  // chunk sums are combined in chunk order.  The summation tree (chunks -> parts -> total) depends only on n.
+  static constexpr int kPartChunks = 8;
+  int nparts() const { return ((n + 255) / 256 + kPartChunks - 1) / kPartChunks; }
+  void acme_part(int p, double p0r, double p1r, double* pp) const {
+    const int nchunk = (n + 255) / 256, lo = p * kPartChunks, hi = std::min(nchunk, lo + kPartChunks);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = -DBL_MAX, pc[5];
+    for (int c = lo; c < hi; ++c) {
+      acme_chunk(c * 256, p0r, p1r, pc);
+      a0 += pc[0];
+      a1 += pc[1];
+      a2 += pc[2];
+      a3 += pc[3];
+      a4 = std::max(a4, pc[4]);
+    }
+    pp[0] = a0;
+    pp[1] = a1;
+    pp[2] = a2;
+    pp[3] = a3;
+    pp[4] = a4;
   }
 
   double acme(double p0r, double p1r) const;  // phasing.py:100-122, one pass (defined after Pool)
+  void acme_batch(const double* p01r, int count, double* out) const;
+  // combine the per-part partial sums serially in part order: the value does not depend on the team
+  // size or on batching (the optimiser's path must be repeatable)
+  template <class F>
+  double acme_combine(int nchunk, F&& chunk_sums) const {
+    double s_ds = 0, s_dslog = 0, s_as = 0, s_as2 = 0, dmax = -DBL_MAX;
+    for (int c = 0; c < nchunk; ++c) {
+      const double* pc = chunk_sums(c);
+      s_ds += pc[0];
+      s_dslog += pc[1];
+      s_as += pc[2];
+      s_as2 += pc[3];
+      dmax = std::max(dmax, pc[4]);
+    }
+    // H = -sum p ln p with p = ds / S, zeros skipped  ==  ln S - (sum ds ln ds) / S
+    const double h = std::log(s_ds) - s_dslog / s_ds;
+    const double pfun = s_as < 0 ? s_as2 : 0.0;
+    return (h + 1000.0 * pfun) / (double)n / dmax;
+  }
 
   double peak_minima(double p0r, double p1r) const {  // phasing.py:125-139
     const int start = std::max(0, target_idx - index_width), end = std::min(n, target_idx + index_width);
@@ -97,6 +205,23 @@ struct Solver {
     return neg * 5.0 - pos;
   }
 
+  // `count` parameter vectors (nx values each, stride 2) -> out[count]; ACME evaluations share one
+  // hand-off to the worker team
+  void score_batch(const double* xs, int nx, int count, double* out) {
+    const double kRad = M_PI / 180.0;
+    if (method != 0 || x_range == 0 || count == 1) {
+      for (int e = 0; e < count; ++e) out[e] = score(xs + 2 * e, nx);
+      return;
+    }
+    nfev += count;
+    std::vector<double> pr(2 * count);
+    for (int e = 0; e < count; ++e) {
+      pr[2 * e] = xs[2 * e] * kRad;
+      pr[2 * e + 1] = (nx > 1 ? xs[2 * e + 1] : 0.0) * kRad;
+    }
+    acme_batch(pr.data(), count, out);
+  }
+
   double score(const double* x, int nx) {
     ++nfev;
     const double kRad = M_PI / 180.0;  // np.radians
@@ -120,7 +245,7 @@ struct Solver {
 // generation counter, every thread does its chunks, the caller combines the per-chunk partial sums
 // serially in chunk order (so the value is independent of the thread count).
 struct Pool {
-  static constexpr int kMaxWorkers = 31, kMaxLocal = 32;
+  static constexpr int kMaxWorkers = 31, kMaxLocal = 128;
   // One slot per team member: its acknowledgement AND its chunk partial sums share the same cache
   // lines, so the caller pays one coherence miss per worker (prefetched together), not one per flag
   // plus one per result line, and nobody does a contended read-modify-write.
@@ -136,16 +261,22 @@ struct Pool {
   Slot slot[kMaxWorkers + 1];
   // current job
   const Solver* s = nullptr;
-  double p0r = 0, p1r = 0;
-  int nchunk = 0, team = 1;
+  const double* params = nullptr;  // (p0, p1) in radians per evaluation of the job
+  int nchunk = 0, neval = 1, team = 1;
 
   static Pool& get() {
     static Pool* p = new Pool();  // intentionally leaked: workers may outlive static destruction
     return *p;
   }
-  void run_share(int id) {  // chunks id, id + team, ... -> slot[id].sums[local]
+  // task j = evaluation j / nchunk, part j % nchunk (nchunk = parts per evaluation); member id takes tasks
+  // id, id + team, ... -> slot[id].sums[local]
+  void run_share(int id) {
     int local = 0;
-    for (int c = id; c < nchunk; c += team, ++local) s->acme_chunk(c * 256, p0r, p1r, slot[id].sums + 5 * local);
+    const int ntask = nchunk * neval;
+    for (int j = id; j < ntask; j += team, ++local) {
+      const int e = j / nchunk, c = j - e * nchunk;
+      s->acme_part(c, params[2 * e], params[2 * e + 1], slot[id].sums + 5 * local);
+    }
   }
   void worker(int id) {
     uint64_t seen = 0;
@@ -187,13 +318,13 @@ struct Pool {
   }
   void park() { state.store(0, std::memory_order_release); }
   bool active() const { return state.load(std::memory_order_acquire) == 1; }
-  bool fits(int chunks, int t) const { return t - 1 <= (int)th.size() && (chunks + t - 1) / t <= kMaxLocal; }
-  // partial sums of chunk c after eval(): slot[c % team].sums[5 * (c / team)]
-  const double* chunk_sums(int c) const { return slot[c % team].sums + 5 * (c / team); }
-  void eval(const Solver* sv, double a, double b, int chunks, int t) {
+  bool fits(int tasks, int t) const { return t - 1 <= (int)th.size() && (tasks + t - 1) / t <= kMaxLocal; }
+  // partial sums of task j after eval(): slot[j % team].sums[5 * (j / team)]
+  const double* task_sums(int j) const { return slot[j % team].sums + 5 * (j / team); }
+  void eval(const Solver* sv, const double* p01r, int count, int chunks, int t) {
     s = sv;
-    p0r = a;
-    p1r = b;
+    params = p01r;
+    neval = count;
     nchunk = chunks;
     team = t;
     const uint64_t g = gen.fetch_add(1, std::memory_order_release) + 1;
@@ -205,32 +336,34 @@ struct Pool {
 };
 
 double Solver::acme(double p0r, double p1r) const {
-  const int nn = n, nchunk = (nn + 255) / 256;
+  double out;
+  const double p[2] = {p0r, p1r};
+  acme_batch(p, 1, &out);
+  return out;
+}
+
+void Solver::acme_batch(const double* p01r, int count, double* out) const {
+  const int nn = n, nchunk = nparts();  // work units per evaluation
   Pool& pool = Pool::get();
   const bool par = threads > 1 && nn >= 2048 && pool.active() && pool.fits(nchunk, threads);
-  double local[5];
-  if (par) pool.eval(this, p0r, p1r, nchunk, threads);
-  // per-chunk partial sums are combined serially in chunk order: the value does not depend on the
-  // team size (the optimiser's path must be repeatable)
-  double s_ds = 0, s_dslog = 0, s_as = 0, s_as2 = 0, dmax = -DBL_MAX;
-  for (int c = 0; c < nchunk; ++c) {
-    const double* pc;
-    if (par) {
-      pc = pool.chunk_sums(c);
-    } else {
-      acme_chunk(c * 256, p0r, p1r, local);
-      pc = local;
+  if (!par) {
+    for (int e = 0; e < count; ++e) {
+      double local[5];
+      out[e] = acme_combine(nchunk, [&](int c) {
+        acme_part(c, p01r[2 * e], p01r[2 * e + 1], local);
+        return (const double*)local;
+      });
     }
-    s_ds += pc[0];
-    s_dslog += pc[1];
-    s_as += pc[2];
-    s_as2 += pc[3];
-    dmax = std::max(dmax, pc[4]);
+    return;
   }
-  // H = -sum p ln p with p = ds / S, zeros skipped  ==  ln S - (sum ds ln ds) / S
-  const double h = std::log(s_ds) - s_dslog / s_ds;
-  const double pfun = s_as < 0 ? s_as2 : 0.0;
-  return (h + 1000.0 * pfun) / (double)n / dmax;
+  // as many evaluations per hand-off as the per-member result slots hold
+  const int per = std::max(1, (Pool::kMaxLocal * threads) / nchunk);
+  for (int e0 = 0; e0 < count; e0 += per) {
+    const int g = std::min(per, count - e0);
+    pool.eval(this, p01r + 2 * e0, g, nchunk, threads);
+    for (int e = 0; e < g; ++e)
+      out[e0 + e] = acme_combine(nchunk, [&](int c) { return pool.task_sums(e * nchunk + c); });
+  }
 }
 
 }  // namespace
@@ -258,11 +391,16 @@ void* xm_solver_create(const double* slice_re_im, const double* coords, int n, d
   s->x_range = cmax - cmin;
   const int hw = (int)std::thread::hardware_concurrency();
   s->threads = std::max(1, std::min(16, hw / 2));
+  if (const char* e = std::getenv("XM_SOLVER_BATCH")) s->batch = std::max(1, std::atoi(e));
   for (int k = 0; k < n; ++k) {
     s->re[k] = slice_re_im[2 * k];
     s->im[k] = slice_re_im[2 * k + 1];
     s->u[k] = s->x_range == 0 ? 0.0 : (coords[k] - pivot) / s->x_range;
   }
+  s->du = (s->u[n - 1] - s->u[0]) / (double)(n - 1);
+  double dev = 0;
+  for (int k = 0; k < n; ++k) dev = std::max(dev, std::fabs(s->u[k] - (s->u[0] + (double)k * s->du)));
+  s->uniform = dev <= 4e-15 && !std::getenv("XM_SOLVER_NO_RECURRENCE");
   return s;
 }
 
@@ -285,6 +423,13 @@ int xm_solver_set_threads(void* h, int threads) {
 }
 
 int xm_solver_get_threads(void* h) { return ((Solver*)h)->threads; }
+
+// `count` parameter vectors, 2 doubles apart (p0[, p1] in degrees) -> out[count]
+void xm_solver_score_batch(void* h, const double* xs, int nx, int count, double* out) {
+  ((Solver*)h)->score_batch(xs, nx, count, out);
+}
+
+int xm_solver_get_batch(void* h) { return ((Solver*)h)->batch; }
 
 // One search at a time owns the pool (two Python threads may call xm_solver_de concurrently).
 static std::mutex g_search_mu;
