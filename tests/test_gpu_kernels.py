@@ -52,7 +52,7 @@ def test_fft_matches_numpy(dev, oracle, n, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
-@pytest.mark.parametrize("n", [7, 8, 256, 1000, 1536, 4096])
+@pytest.mark.parametrize("n", [7, 8, 256, 1000, 1536, 3072, 4096, 5120])
 def test_fft_flags(dev, oracle, n, dtype):
     x = _rand((5, n), dtype, seed=3)
     xd = dev.to_device(x)

@@ -420,9 +420,13 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
 // middle-stage twiddles in LDS, next pair prefetched).  Any direct plan with NT >= 64 whose 16-byte
 // exchange buffer fits the LDS; rolls, inverse, window, phase and arg-max as in k_pipe.
 // =================================================================================================
+// waves per SIMD the register allocator must leave room for: as many workgroups per CU as the LDS holds
+// (at most two)
 template <class PL>
 constexpr int fft2_waves() {
-  int w = PL::NT / 128;
+  const long lds = (long)BlockFFT<xm_f2, PL>::lds_elems() * (long)sizeof(Cx<xm_f2>);
+  const int wg = 160 * 1024 / lds >= 2 ? 2 : 1;
+  int w = wg * PL::NT / 256;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 

@@ -36,14 +36,14 @@
   X(4, 1, 4)                  \
   X(8, 1, 8)                  \
   X(384, 16, 24, 4, 4)        \
-  X(768, 32, 24, 8, 4)        \
-  X(1536, 64, 24, 8, 8)       \
-  X(3072, 64, 48, 8, 8)       \
-  X(6144, 128, 48, 16, 8)     \
+  X(768, 64, 12, 4, 4, 4)     \
+  X(1536, 128, 12, 4, 4, 4, 2) \
+  X(3072, 256, 12, 4, 4, 4, 4) \
+  X(6144, 512, 12, 4, 4, 4, 4, 2) \
   X(640, 32, 20, 4, 4, 2)     \
-  X(1280, 32, 40, 8, 4)       \
-  X(2560, 64, 40, 8, 8)       \
-  X(5120, 128, 40, 8, 8, 2)
+  X(1280, 64, 20, 4, 4, 4)    \
+  X(2560, 128, 20, 4, 4, 4, 2) \
+  X(5120, 256, 20, 4, 4, 4, 4)
 
 // complex64 only: 16384 x 16 B does not fit the 160 KiB LDS
 #define XM_PLANS_C64_ONLY(X) X(16384, 1024, 16, 16, 16, 4)
