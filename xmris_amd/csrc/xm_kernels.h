@@ -543,6 +543,110 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
 }
 
 // =================================================================================================
+// Scalar persistent kernel (complex128: no packed f64 math exists, so one spectrum per workgroup pass):
+// the structure of k_fft2 -- persistent workgroups, window and last-stage twiddles in registers,
+// middle-stage twiddles in LDS, the next spectrum prefetched while the current one is transformed.
+// =================================================================================================
+template <class T, class PL>
+constexpr int fft1_waves() {
+  const long lds = (long)BlockFFT<T, PL>::lds_elems() * (long)sizeof(Cx<T>);
+  const int wg = 160 * 1024 / lds >= 2 ? 2 : 1;
+  int w = wg * PL::NT / 256;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
+template <class T, class PL, int MODE>
+__global__ __launch_bounds__(PL::NT, (fft1_waves<T, PL>())) void k_fft1(PipeArgs<T> A) {
+  constexpr int N = PL::N, NT = PL::NT, P = PL::P;
+  constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  using FFT = BlockFFT<T, PL>;
+  using HT = HotTw<T, PL>;
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem);
+  Cx<T>* mid = lds + FFT::lds_elems();
+  T* red_v = reinterpret_cast<T*>(mid + HT::mid_lds_size());
+  int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
+  const int t = threadIdx.x;
+
+  HT tw;
+  tw.load(A.tw, t);
+  if constexpr (HT::mid_in_lds()) {
+    tw.mid = mid;
+    for (int i = t; i < HT::mid_size(); i += NT) mid[i] = A.tw[i];
+  } else {
+    tw.mid = A.tw;
+  }
+  T w[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    int j = t + NT * q - A.in_shift;
+    if (j < 0) j += N;
+    const bool ok = (unsigned)(j - A.pad_left) < (unsigned)A.n_in;
+    w[q] = ok ? (A.window ? A.window[j] * A.scale : A.scale) : T(0);
+  }
+  __syncthreads();
+
+  const unsigned last_in = (unsigned)A.n_in - 1u;
+  Cx<T> xr[P];
+  auto fetch = [&](long long s, int tt, int shift, int padl, unsigned lastv) {
+    const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      int j = tt + NT * q - shift;
+      if (j < 0) j += N;
+      xr[q] = row[min((unsigned)(j - padl), lastv)];  // clamped; zero-filled positions have w = 0
+    }
+  };
+  long long s = blockIdx.x;
+  if (s < A.n_batch) fetch(s, t, A.in_shift, A.pad_left, last_in);
+
+  for (; s < A.n_batch; s += gridDim.x) {
+    int tt = t, osh = A.out_shift, ish = A.in_shift, padl = A.pad_left;
+    unsigned lastv = last_in;
+    asm volatile("" : "+v"(tt));  // keep per-lane address arithmetic inside the loop (see k_zf2)
+    asm volatile("" : "+s"(osh));
+    asm volatile("" : "+s"(ish));
+    asm volatile("" : "+s"(padl));
+    asm volatile("" : "+s"(lastv));
+    Cx<T> v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      v[q] = xr[q] * w[q];
+      if (A.inverse) v[q].im = -v[q].im;
+    }
+    if (s + gridDim.x < A.n_batch) fetch(s + gridDim.x, tt, ish, padl, lastv);
+
+    FFT::run(v, lds, tw, tt);
+
+    if constexpr (AMAX) {
+      T bv = T(-1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) bv = fmax(bv, v[q].re * v[q].re + v[q].im * v[q].im);
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        int k = tt + NT * q + osh;
+        if (k >= N) k -= N;
+        bi = min(bi, (v[q].re * v[q].re + v[q].im * v[q].im) == bv ? k : 0x7fffffff);
+      }
+      amax_reduce_store<T, NT>(bv, bi, tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+    }
+    if constexpr (WRITE) {
+      Cx<T>* __restrict__ orow = A.out + s * (long long)N;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        int k = tt + NT * q + osh;
+        if (k >= N) k -= N;
+        Cx<T> y = v[q];
+        if (A.inverse) y.im = -y.im;
+        if constexpr (PHASE) y = y * A.phase[k];
+        orow[k] = y;
+      }
+    }
+  }
+}
+
+// =================================================================================================
 // Bluestein (chirp-z) kernel for lengths without a direct plan.  PL = power-of-two plan of
 // length M >= 2n-1.   X[m] = a[m] * sum_k (z[k] a[k]) b[m-k],  a[k] = e^{-i pi k^2/n}, b = conj(a).
 // aux = a (n entries), aux2 = FFT_M(b wrapped) / M (M entries), both fp64-computed on the host.
