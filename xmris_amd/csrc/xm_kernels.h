@@ -713,6 +713,179 @@ __global__ __launch_bounds__(PL::NT* SPB) void k_bluestein(PipeArgs<T> A) {
 }
 
 // =================================================================================================
+// Persistent Bluestein kernel: the chirp-z of k_bluestein with the structure of k_fft2 / k_fft1.
+// V = xm_f2: two spectra ride in the packed-f32 lanes (rows 2g, 2g+1); V = double: one spectrum per pass.
+// Per-thread invariants live in registers for the whole launch: the chirp a[pos] (0 beyond n), the
+// window weight of each position (0 where the padded input is structurally zero), the chirp spectrum
+// aux2[pos] and the last-stage twiddles; the next rows are prefetched while the two FFTs of the current
+// ones run.
+// =================================================================================================
+template <class V, class PL>
+constexpr int blue_waves() {
+  // ~165 VGPRs of per-thread state: two waves per SIMD at most (four would spill ~50 registers, measured 25 % slower)
+  const long lds = (long)BlockFFT<V, PL>::lds_elems() * (long)sizeof(Cx<V>);
+  const int wg = 160 * 1024 / lds >= 2 ? 2 : 1;
+  int w = wg * PL::NT / 256;
+  return w < 1 ? 1 : (w > 2 ? 2 : w);
+}
+
+template <class V, class PL, int MODE>
+__global__ __launch_bounds__(PL::NT, (blue_waves<V, PL>())) void k_blue(PipeArgs<typename ScalarOf<V>::type> A) {
+  using T = typename ScalarOf<V>::type;
+  constexpr bool PACKED = sizeof(V) != sizeof(T);
+  constexpr int NS = PACKED ? 2 : 1;  // spectra per pass
+  constexpr int NT = PL::NT, P = PL::P;
+  // M >= 2n - 1 is the next power of two, so n <= M/2: positions t + NT*q with q >= P/2 never hold input
+  // samples and never produce outputs -- only the lower half of the per-thread slots carries chirps,
+  // window weights, prefetched samples and results
+  constexpr int PH = P / 2;
+  constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  using FFT = BlockFFT<V, PL>;
+  using HT = HotTw<T, PL>;
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
+  Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
+  T* red_v = reinterpret_cast<T*>(mid + HT::mid_lds_size());
+  int* red_i = reinterpret_cast<int*>(red_v + NS * (NT / XM_WAVE + 1));
+  const int t = threadIdx.x;
+  const int n = A.n;
+
+  HT tw;
+  tw.load(A.tw, t);
+  if constexpr (HT::mid_in_lds()) {
+    tw.mid = mid;
+    for (int i = t; i < HT::mid_size(); i += NT) mid[i] = A.tw[i];
+  } else {
+    tw.mid = A.tw;
+  }
+  // position pos = t + NT*q of the length-M convolution input holds padded sample j = (pos - in_shift) mod n
+  // = input sample j - pad_left, for pos < n
+  Cx<T> ca[PH], cb[P];
+  T wg[PH];
+#pragma unroll
+  for (int q = 0; q < P; ++q) cb[q] = A.aux2[t + NT * q];
+#pragma unroll
+  for (int q = 0; q < PH; ++q) {
+    const int pos = t + NT * q;
+    ca[q] = pos < n ? A.aux[pos] : mk<T>(T(0), T(0));
+    int j = pos - A.in_shift;
+    if (j < 0) j += n;
+    const bool ok = pos < n && (unsigned)(j - A.pad_left) < (unsigned)A.n_in;
+    wg[q] = ok ? (A.window ? A.window[j] : T(1)) : T(0);
+  }
+  __syncthreads();
+
+  const long long ngroups = (A.n_batch + NS - 1) / NS;
+  const unsigned last_in = (unsigned)A.n_in - 1u;
+  Cx<T> xr[NS][PH];
+  auto fetch = [&](long long g, int tt, int shift, int padl, unsigned lastv, int nn) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      long long s = NS * g + u;
+      if (s >= A.n_batch) s = NS * g;  // odd tail: duplicate row
+      const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
+#pragma unroll
+      for (int q = 0; q < PH; ++q) {
+        int j = tt + NT * q - shift;
+        if (j < 0) j += nn;
+        xr[u][q] = row[min((unsigned)(j - padl), lastv)];  // clamped; positions without data have wg = 0
+      }
+    }
+  };
+  long long g = blockIdx.x;
+  if (g < ngroups) fetch(g, t, A.in_shift, A.pad_left, last_in, n);
+
+  for (; g < ngroups; g += gridDim.x) {
+    int tt = t, osh = A.out_shift, ish = A.in_shift, padl = A.pad_left, nn = n;
+    unsigned lastv = last_in;
+    asm volatile("" : "+v"(tt));  // keep per-lane address arithmetic inside the loop (see k_zf2)
+    asm volatile("" : "+s"(osh));
+    asm volatile("" : "+s"(ish));
+    asm volatile("" : "+s"(padl));
+    asm volatile("" : "+s"(lastv));
+    asm volatile("" : "+s"(nn));
+    Cx<V> v[P];
+#pragma unroll
+    for (int q = PH; q < P; ++q) {
+      v[q].re = V(0);
+      v[q].im = V(0);
+    }
+#pragma unroll
+    for (int q = 0; q < PH; ++q) {
+      Cx<V> x;
+      if constexpr (PACKED) {
+        x.re = V{xr[0][q].re, xr[1][q].re};
+        x.im = V{xr[0][q].im, xr[1][q].im};
+      } else {
+        x = xr[0][q];
+      }
+      if (A.inverse) x.im = -x.im;
+      v[q] = (x * ca[q]) * wg[q];
+    }
+    if (g + gridDim.x < ngroups) fetch(g + gridDim.x, tt, ish, padl, lastv, nn);
+
+    FFT::run(v, lds, tw, tt);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      v[q] = v[q] * cb[q];
+      v[q].im = -v[q].im;  // conj -> inverse transform via the forward one
+    }
+    FFT::run(v, lds, tw, tt);
+
+    // X[m] = conj(v[m]) a[m] scale for m < n, at output index (m + out_shift) mod n
+    T bv[NS];
+    int bi[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      bv[u] = T(-1);
+      bi[u] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int q = 0; q < PH; ++q) {
+      const int m = tt + NT * q;
+      int k = m + osh;
+      if (k >= nn) k -= nn;
+      Cx<V> y = v[q];
+      y.im = -y.im;
+      y = (y * ca[q]) * A.scale;
+      if (A.inverse) y.im = -y.im;
+      if constexpr (AMAX) {
+        const V m2 = y.re * y.re + y.im * y.im;
+        if (m < nn) {
+          if constexpr (PACKED) {
+            amax_take(bv[0], bi[0], m2.x, k);
+            amax_take(bv[NS - 1], bi[NS - 1], m2.y, k);
+          } else {
+            amax_take(bv[0], bi[0], m2, k);
+          }
+        }
+      }
+      if constexpr (WRITE) {
+        if (m < nn) {
+          if constexpr (PHASE) y = y * A.phase[k];
+          if constexpr (PACKED) {
+            const long long s0 = NS * g, s1 = NS * g + 1;
+            A.out[s0 * (long long)nn + k] = mk<T>(y.re.x, y.im.x);
+            if (s1 < A.n_batch) A.out[s1 * (long long)nn + k] = mk<T>(y.re.y, y.im.y);
+          } else {
+            A.out[g * (long long)nn + k] = y;
+          }
+        }
+      }
+    }
+    if constexpr (AMAX) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const long long s = NS * g + u;
+        const bool live = s < A.n_batch;
+        amax_reduce_store<T, NT>(bv[u], bi[u], tt, live, live ? s : NS * g, A.absmax2, A.argidx,
+                                 red_v + u * (NT / XM_WAVE + 1), red_i + u * (NT / XM_WAVE + 1));
+      }
+    }
+  }
+}
+
+// =================================================================================================
 // Element-wise staged kernels (one complex sample per thread per step, grid-stride).
 // =================================================================================================
 template <class T>
