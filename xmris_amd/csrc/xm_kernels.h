@@ -991,14 +991,27 @@ __global__ __launch_bounds__(1024) void k_argmax_final(const T* __restrict__ abs
   __shared__ long long red_i[16];
   T bv = T(-1);
   long long bi = 0x7fffffffffffffffLL;
-  for (long long b = threadIdx.x; b < n_batch; b += 1024) {
-    const T v = absmax2[b];
-    const long long f = b * (long long)n + argidx[b];
-    if (v > bv || (v == bv && f < bi)) {
-      bv = v;
-      bi = f;
+  // One workgroup, so the scan is latency bound: every thread scans the VALUES of its rows with UN
+  // independent loads in flight per round and remembers the first row holding its maximum; the index
+  // array is read once per thread, for that row only.
+  constexpr int UN = 16;
+  for (long long b0 = threadIdx.x; b0 < n_batch; b0 += 1024 * UN) {
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long b = b0 + 1024LL * u;
+      v[u] = b < n_batch ? absmax2[b] : T(-1);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long b = b0 + 1024LL * u;
+      if (v[u] > bv) {  // strict: keeps the lowest row among equal values (rows ascend with u and b0)
+        bv = v[u];
+        bi = b;
+      }
     }
   }
+  if (bi != 0x7fffffffffffffffLL) bi = bi * (long long)n + argidx[bi];  // one index load per thread
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     T ov = shfl_xor_t(bv, m);

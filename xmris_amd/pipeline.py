@@ -86,8 +86,8 @@ class AutophaseResult:
 class Selection:
     """Device-side selection stage of autophase, queued without any host synchronisation right behind a
     pre-pass: global arg-max reduction -> gather of the winning FID (row index read from device memory)
-    -> its spectrum recomputed in complex128 -> asynchronous copies of (max, flat index, slice) into
-    pinned host memory, closed by an event.  `wait()` blocks on that event only, so kernels queued
+    -> its spectrum recomputed in complex128, with (max, flat index, slice) written by the kernels straight
+    into pinned host memory, closed by an event.  `wait()` blocks on that event only, so kernels queued
     later on the same stream (another dataset's main pass) do not delay the host solver."""
 
     def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False):
@@ -98,28 +98,29 @@ class Selection:
         if plan.window64 is None:
             plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x2.device, torch.float64)
         self.n = n
-        self.gmax, self.gflat = dev.argmax_reduce_async(absmax2, argidx, n)
-        x1 = dev.gather_row_c128(x2, self.gflat, n)
-        sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out
-        # pinned staging buffers are reused across datasets (two sets: a streaming caller keeps at most
-        # two selections in flight); allocating pinned memory per call costs more than the copies
+        # Results go straight into pinned host memory (device-accessible at the same address on ROCm): the
+        # reduction writes (max, flat index) there, the gather reads the index back from there, and the
+        # complex128 spectrum kernel stores its 128 KiB row there -- no memcpy nodes on the stream.  The
+        # buffers are reused across datasets (two sets: a streaming caller keeps at most two selections
+        # in flight); allocating pinned memory per call costs more than the transfers.
+        rdt = absmax2.dtype
         pool = plan.extra.setdefault("pinned", [])
         turn = plan.extra["turn"] = (plan.extra.get("turn", -1) + 1) % 2
         if len(pool) <= turn:
-            pool.append((torch.empty(1, dtype=self.gmax.dtype, pin_memory=True),
+            pool.append((torch.empty(1, dtype=rdt, pin_memory=True),
                          torch.empty(1, dtype=torch.int64, pin_memory=True),
-                         torch.empty(n, dtype=torch.complex128, pin_memory=True)))
-        self.h_max, self.h_flat, self.h_slice = pool[turn]
-        self.h_max.copy_(self.gmax, non_blocking=True)
-        self.h_flat.copy_(self.gflat, non_blocking=True)
-        self.h_slice.copy_(sl[0], non_blocking=True)
-        self._keep = (x1, sl)
+                         torch.empty((1, n), dtype=torch.complex128, pin_memory=True),
+                         torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device)))
+        self.h_max, self.h_flat, self.h_slice, x1 = pool[turn]
+        dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
+        dev.gather_row_c128(x2, self.h_flat, n, out=x1)
+        dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
         self.event = torch.cuda.Event()
         self.event.record()
 
     def wait(self):
         self.event.synchronize()
-        sl = self.h_slice.numpy().copy()
+        sl = self.h_slice[0].numpy().copy()
         flat = int(self.h_flat.item())
         if self.index_from_slice:  # index along the axis = first arg-max of the (fp64) winning spectrum
             flat = (flat // self.n) * self.n + int(np.argmax(np.abs(sl)))
