@@ -78,6 +78,8 @@ def main():
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --share-gpu) to exercise "
                          "the multi-rank code path on a single-GPU box; the driver uses the default (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--exchange", choices=["shm", "gloo"], default="shm",
+                    help="N > 1: the O(1) host exchange goes through a shared-memory page (one node) or gloo")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +100,7 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = None
     host_group = None
+    shm = None
     if world > 1:
         import torch.distributed as dist
 
@@ -110,6 +113,13 @@ def main():
         # the O(1) arg-max exchange and (p0, p1) broadcast are host-side metadata: a gloo group keeps
         # them from queueing behind the kernels of other datasets already on the GPU stream
         host_group = dist.new_group(backend="gloo")
+        # on one node the same exchange goes through a shared-memory page (microseconds instead of two
+        # loopback collectives per dataset); every rank must agree on the choice, so failures are gathered
+        if args.exchange == "shm":
+            try:
+                shm = sharding.ShmExchange.create(dist, group=host_group)
+            except OSError as e:  # raised on every rank alike: all of them fall back to gloo
+                print(f"[rank {rank}] shared-memory exchange unavailable ({e}); using gloo", file=sys.stderr)
 
     cdtype = torch.complex64 if args.dtype == "c64" else torch.complex128
     rdtype = torch.float32 if args.dtype == "c64" else torch.float64
@@ -158,7 +168,10 @@ def main():
             state = {}
 
             def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
-                owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev, group=host_group)
+                if shm is not None:
+                    owner, gwin, _ = shm.exchange_argmax(amax, gflat)
+                else:
+                    owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev, group=host_group)
                 state["owner"] = owner
                 state["t_x1"] = time.perf_counter()
                 return owner == rank, gwin
@@ -170,7 +183,10 @@ def main():
             res, mine = pipeline.select_and_solve(x, plan, absmax2[b], argidx[b], exchange=exchange,
                                                   rank_offset_rows=rank * nv, on_host_phase=queue_next,
                                                   selection=sel[b])
-            p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev, group=host_group)
+            if shm is not None:
+                p0, p1 = shm.broadcast_params([res.p0, res.p1], state["owner"])
+            else:
+                p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev, group=host_group)
             t2 = time.perf_counter()
             ph = pipeline.upload_phase_table(plan, x, p0, p1, res.pivot)
             t3 = time.perf_counter()

@@ -53,6 +53,20 @@ def _worker(rank, world, port, tie, q):
         flat = int(np.argmax(np.abs(spec)))
         amax = float(np.abs(spec).reshape(-1)[flat])
         owner, gflat, gmax = sharding.exchange_argmax(amax, lo * n + flat, dist)
+        # the single-node shared-memory exchange must agree with the collective one, dataset after dataset
+        shm = sharding.ShmExchange.create(dist)
+        assert shm.exchange_argmax(amax, lo * n + flat) == (owner, gflat, gmax)
+        assert shm.broadcast_params([1.5 + owner, -2.0], owner) == [1.5 + owner, -2.0]
+        rng = np.random.default_rng(100 + rank)
+        for it in range(300):  # ranks run ahead of each other at random: two banks must be enough
+            mine = (float(rng.integers(0, 4)), int(rng.integers(0, 1000)))
+            ref = sharding.exchange_argmax(mine[0], mine[1], dist)
+            if rng.random() < 0.3:
+                import time
+                time.sleep(float(rng.random()) * 1e-3)
+            assert shm.exchange_argmax(*mine) == ref, it
+            vals = shm.broadcast_params([it + 0.25, float(rank)], ref[0])
+            assert vals == [it + 0.25, float(ref[0])], it
         k = gflat % n
         pivot = float(freq[k])
         params = [0.0, 0.0]
