@@ -255,7 +255,9 @@ def main():
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_zf2<float, FftPlan<4096,256,16,16,16>, 3> (main pass: zero-fill+window+FFT+fftshift+phase)",
+            "bound": "hbm", "kernel": (("k_zf2<float, FftPlan<4096,256,16,16,16>, 3>" if args.dtype == "c64" else
+                                        "k_zf2<double, FftPlan<4096,512,8,8,8,8>, 3>") if (nt, N) == (4096, 8192)
+                                       else "xm_pipeline_fused main pass") + " (zero-fill+window+FFT+fftshift+phase)",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None),
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01/pmc_main_kernel.txt",
