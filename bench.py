@@ -96,6 +96,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if args.share_gpu:
         local_rank = 0
+    local_rank %= max(1, torch.cuda.device_count())  # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
