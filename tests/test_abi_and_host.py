@@ -264,3 +264,37 @@ def test_native_solver_replicates_scipy_differential_evolution():
         obj.set_threads(thr)
         vals.append(obj([12.5, -321.0]))
     assert vals[0] == vals[1] == vals[2]
+
+
+def test_native_solver_speculative_batches_do_not_change_the_search():
+    """xm_solver_de evaluates up to XM_SOLVER_BATCH trials speculatively per hand-off and commits them in
+    scipy's order: x, fun, nfev and nit must not depend on the batch size (1 = the sequential schedule) nor
+    on the team size, and xm_solver_score_batch must return xm_solver_score's values."""
+    from xmris_amd import autophase_solver as aps
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "scores.npz"))
+    sl, fr, pv, ti, iw = g["slice"], g["freq"], float(g["pivot"]), int(g["target_idx"]), int(g["index_width"])
+    old = os.environ.get("XM_SOLVER_BATCH")
+    try:
+        for method in aps.METHODS:
+            runs = []
+            for batch, threads in ((1, 1), (4, 0), (7, 3), (30, 0)):
+                os.environ["XM_SOLVER_BATCH"] = str(batch)  # read when the solver handle is created
+                obj = aps.NativeObjective(sl, fr, pv, ti, iw, method)
+                obj.set_threads(threads)
+                for p0_only in (False, True):
+                    before = obj.evaluations()
+                    rc, x, fun, nfev, nit = obj.de(p0_only)
+                    assert obj.evaluations() - before >= nfev
+                    runs.append((batch, p0_only, rc, tuple(x), fun, nfev, nit))
+            ref = {r[1]: r[2:] for r in runs if r[0] == 1}
+            for r in runs:
+                assert r[2:] == ref[r[1]], (method, r[0], r[1])
+            obj = aps.NativeObjective(sl, fr, pv, ti, iw, method)
+            pts = np.array([[12.5, -321.0], [-170.0, 3999.0], [0.0, 0.0], [33.3, 47.1], [179.0, -3999.0]])
+            assert np.array_equal(obj.score_batch(pts), np.array([obj(p) for p in pts]))
+    finally:
+        if old is None:
+            os.environ.pop("XM_SOLVER_BATCH", None)
+        else:
+            os.environ["XM_SOLVER_BATCH"] = old
