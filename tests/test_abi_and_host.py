@@ -298,3 +298,22 @@ def test_native_solver_speculative_batches_do_not_change_the_search():
             os.environ.pop("XM_SOLVER_BATCH", None)
         else:
             os.environ["XM_SOLVER_BATCH"] = old
+
+
+def test_native_acme_objective_on_a_non_uniform_axis_and_ragged_lengths():
+    """The ACME objective has two code paths: the rotation recurrence for a uniformly spaced coordinate (what
+    the path produces) and per-sample sin/cos for any other coordinate; the last 256-sample chunk may be
+    ragged.  Both must match the numpy objective (phasing.py:100-122)."""
+    from xmris_amd import autophase_solver as aps
+
+    rng = np.random.default_rng(3)
+    for n in (2, 17, 255, 256, 257, 1531, 2048, 4099):
+        sl = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        uniform = np.roll(np.fft.fftfreq(n, d=2e-4), n // 2)
+        warped = uniform + 3.0 * np.sin(np.arange(n))  # same range order, not evenly spaced
+        for coords in (uniform, warped):
+            k = int(np.argmax(np.abs(sl)))
+            obj = aps.NativeObjective(sl, coords, float(coords[k]), k, 1, "acme")
+            for p in ([0.0, 0.0], [12.5, -321.0], [-170.0, 3999.0], [179.0, -3999.0]):
+                ref = aps.acme_score(p, sl, coords, float(coords[k]))
+                assert obj(p) == pytest.approx(ref, rel=2e-12, abs=1e-15), (n, p)
