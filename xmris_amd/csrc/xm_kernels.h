@@ -301,6 +301,18 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     const bool ok = (toff + NT * q) < n_in;
     w[q] = ok ? (A.window ? A.window[t + NT * q] * A.scale : A.scale) : T(0);
   }
+  // The pre-pass (arg-max only, packed) has ~50 VGPRs to spare and is instruction bound: it folds the window
+  // into the odd-bin rotation once per launch, R_q = w_q * W_N^{t + NT q}, so that one sample costs two
+  // packed multiplies + two FMAs instead of ~11 scalar operations (window, rotation, W_2P^q, lane packing).
+  constexpr bool FOLD = PACKED && MODE == ZF2_AMAX;
+  Cx<T> wr[FOLD ? P : 1];
+  if constexpr (FOLD) {
+    static_for<0, P>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const Cx<T> r = mul_w<q, 2 * P, T>(rot);
+      wr[q] = mk<T>(r.re * w[q], r.im * w[q]);
+    });
+  }
   __syncthreads();
 
   // FID sample j = t + NT*q of a row lives at row[j - pad_left].  Positions outside the acquired
@@ -332,21 +344,43 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     Cx<T> vo[PACKED ? 1 : P];     // unpacked: the odd-bin half
     static_for<0, P>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      const Cx<T> e = xr[q] * w[q];
-      const Cx<T> o = mul_w<q, 2 * P, T>(e * rot);
-      if constexpr (PACKED) {
-        v[q].re = V{e.re, o.re};
-        v[q].im = V{e.im, o.im};
+      if constexpr (FOLD) {
+        // lane x: x * w (even bins), lane y: x * R_q (odd bins)
+        const V a = V{w[q], wr[q].re};
+        V re = V{xr[q].re, xr[q].re} * a;
+        V im = V{xr[q].im, xr[q].im} * a;
+        re.y = __builtin_fmaf(-xr[q].im, wr[q].im, re.y);
+        im.y = __builtin_fmaf(xr[q].re, wr[q].im, im.y);
+        v[q].re = re;
+        v[q].im = im;
       } else {
-        v[q] = e;
-        vo[q] = o;
+        const Cx<T> e = xr[q] * w[q];
+        const Cx<T> o = mul_w<q, 2 * P, T>(e * rot);
+        if constexpr (PACKED) {
+          v[q].re = V{e.re, o.re};
+          v[q].im = V{e.im, o.im};
+        } else {
+          v[q] = e;
+          vo[q] = o;
+        }
       }
     });
     const long long s2 = s + gridDim.x;
     if (s2 < A.n_batch) {  // prefetch the next FID while this one is transformed
       const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
+      if (nin == NT * P && pl == 0u) {
+        // exactly half full (the 2x zero fill): every slot holds a sample, no clamp -- scalar row base +
+        // compile-time slot offset + one 32-bit lane offset, no per-load vector address arithmetic
+        const unsigned lane_off = tt * CB;  // 32-bit byte offset: lets the load use SGPR base + VGPR offset
 #pragma unroll
-      for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
+        for (int q = 0; q < P; ++q) {
+          const char* rq = reinterpret_cast<const char*>(row + NT * q);
+          xr[q] = *reinterpret_cast<const Cx<T>*>(rq + lane_off);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
+      }
     }
 
     FFT::run(v, lds, tw, (int)tt);
