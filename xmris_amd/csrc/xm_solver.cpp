@@ -3,7 +3,8 @@
 //
 // The reference calls scipy.optimize.differential_evolution(best1bin, tol=0.01, seed=42) with Python
 // objectives (~90 ms for an 8192-point slice).  This file restates
-//   * the three objectives as vectorised C++ (one pass over the slice, OpenMP across cores), and
+//   * the three objectives as vectorised C++ (xm_solver_obj.cpp: one pass over the slice, shared by a small
+//     team of spinning host threads), and
 //   * scipy 1.15.3's DifferentialEvolutionSolver for exactly the configuration the reference uses
 //     (latin-hypercube init, best1bin, dithered mutation U[0.5,1), recombination 0.7, immediate
 //     updating, std/mean convergence) driven by numpy's legacy RandomState(seed) MT19937 stream, so the
