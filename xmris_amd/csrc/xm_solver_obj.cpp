@@ -228,24 +228,16 @@ struct Solver {
     ++nfev;
     const double kRad = M_PI / 180.0;  // np.radians
     const double p0r = x[0] * kRad, p1r = (nx > 1 ? x[1] : 0.0) * kRad;
-    if (method == 0) {
-      if (x_range == 0) {  // scalar phase: same formula with u == 0
-        Solver tmp = *this;
-        std::fill(tmp.u.begin(), tmp.u.end(), 0.0);
-        return tmp.acme(p0r, 0.0);
-      }
-      return acme(p0r, p1r);
-    }
+    if (method == 0) return acme(p0r, x_range == 0 ? 0.0 : p1r);  // zero range: scalar phase (u is all zero)
     return method == 1 ? peak_minima(p0r, p1r) : positivity(p0r, p1r);
   }
 };
 
-
-
-// A few persistent worker threads that SPIN while a search is running (activated by xm_solver_de via
-// Pool::Scope) and sleep on a condition variable otherwise.  One evaluation = publish (p0, p1), bump a
-// generation counter, every thread does its chunks, the caller combines the per-chunk partial sums
-// serially in chunk order (so the value is independent of the thread count).
+// A few persistent worker threads that SPIN while a search is running (between xm_solver_pool_begin / _end,
+// i.e. inside xm_solver_de) and sleep on a condition variable otherwise.  One job = a batch of evaluations:
+// publish their (p0, p1), bump a generation counter, every member takes its share of the work units
+// (evaluation x 2048-sample part), the caller combines the per-part sums serially in part order (so the
+// value is independent of the team size and of the batching).
 struct Pool {
   static constexpr int kMaxWorkers = 31, kMaxLocal = 128;
   // One slot per team member: its acknowledgement AND its chunk partial sums share the same cache
