@@ -168,6 +168,12 @@ CASES = [
     (3, 1531, 1531, 0),
     (3, 700, 1531, 415),
     (9, 100, 128, 0),
+    (6, 2500, 3072, 0),    # 3*2^k: 12 points per thread (k_fft2 pairs / k_fft1)
+    (4, 5120, 5120, 0),    # 5*2^k: 20 points per thread
+    (3, 3000, 6144, 0),
+    (5, 1972, 1972, 0),    # a Bruker FID after the group-delay cut: chirp-z with M = 4096 (k_blue)
+    (3, 900, 1000, 50),    # chirp-z with M = 2048, left pad
+    (2, 3000, 3001, 0),    # chirp-z with M = 8192 (one-spectrum kernel)
 ]
 
 
@@ -192,13 +198,16 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     rd = torch.float32 if dtype == "complex64" else torch.float64
     wd = torch.from_numpy(w).to("cuda", rd)
     phd = torch.from_numpy(ph).to("cuda", xd.dtype)
-    tol = TIGHT[dtype] * (4 if n_out == 1531 else 1)
+    tol = TIGHT[dtype] * (4 if n_out in (1531, 1972, 1000, 3001) else 1)
     # (1) arg-max pre-pass only
     pre = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True)
     amax, flat = dev.argmax_reduce(pre.absmax2, pre.argidx, n_out)
     assert flat == int(np.argmax(np.abs(spec)))
     assert abs(amax - np.abs(spec).max()) < 1e-5 * np.abs(spec).max()
     np.testing.assert_array_equal(pre.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
+    # (1b) value-only pre-pass (the bench's mode): same per-spectrum maxima, bit for bit
+    vo = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True, argmax_value_only=True)
+    assert torch.equal(vo.absmax2, pre.absmax2)
     # (2) unphased spectrum + arg-max in one launch
     both = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_argmax=True)
     assert _relerr(both.out.cpu().numpy(), spec) < tol
