@@ -265,7 +265,7 @@ enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4 };
 template <class T, class PL>
 constexpr int zf2_waves() {
   int w = PL::NT / 128;  // 2 workgroups of NT threads over 4 SIMDs
-  if (sizeof(T) == 8) w /= 2;
+  if (sizeof(T) == 8) w /= 2;  // complex128 (8 points per thread): ~170 VGPRs, one workgroup per CU
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
   // into the odd-bin rotation once per launch, R_q = w_q * W_N^{t + NT q}, so that one sample costs two
   // packed multiplies + two FMAs instead of ~11 scalar operations (window, rotation, W_2P^q, lane packing).
   constexpr bool FOLD = PACKED && MODE == ZF2_AMAX;
+  constexpr bool SEQ = !PACKED && MODE == ZF2_AMAX;
   Cx<T> wr[FOLD ? P : 1];
   if constexpr (FOLD) {
     static_for<0, P>([&](auto qc) {
@@ -340,6 +341,64 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     asm volatile("" : "+s"(nin));
     asm volatile("" : "+s"(pl));
     const unsigned toff2 = tt - pl;
+    auto prefetch = [&]() {  // the next FID, while the current one is transformed
+      const long long s2 = s + gridDim.x;
+      if (s2 < A.n_batch) {
+        const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
+        if (nin == NT * P && pl == 0u) {
+          // exactly half full (the 2x zero fill): every slot holds a sample, no clamp -- scalar row base +
+          // compile-time slot offset + one 32-bit lane offset, no per-load vector address arithmetic
+          const unsigned lane_off = tt * CB;  // 32-bit byte offset: lets the load use SGPR base + VGPR offset
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const char* rq = reinterpret_cast<const char*>(row + NT * q);
+            xr[q] = *reinterpret_cast<const Cx<T>*>(rq + lane_off);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
+        }
+      }
+    };
+    if constexpr (SEQ) {
+      // complex128 arg-max pre-pass: the halves run one after the other anyway, so each is reduced to its
+      // (max, first index) as soon as it is transformed and only ONE half-spectrum is ever live in registers
+      // (both halves + the prefetched FID did not fit 256 VGPRs); the odd half is formed from the samples
+      // after the even half is done, the prefetch overlaps the second transform.
+      const unsigned t2 = 2u * tt;
+      Cx<T> h[P];
+      T bv = T(-1);
+      int bi = 0x7fffffff;
+      auto reduce_half = [&](unsigned odd) {
+        T hv = T(-1);
+#pragma unroll
+        for (int q = 0; q < P; ++q) hv = fmax(hv, h[q].re * h[q].re + h[q].im * h[q].im);
+        int hi = 0;
+        if (!A.amax_value_only) {  // wave-uniform
+          hi = 0x7fffffff;
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2 + odd);
+            hi = min(hi, (h[q].re * h[q].re + h[q].im * h[q].im) == hv ? k0 : 0x7fffffff);
+          }
+        }
+        amax_take(bv, bi, hv, hi);
+      };
+#pragma unroll
+      for (int q = 0; q < P; ++q) h[q] = xr[q] * w[q];
+      FFT::run(h, lds, tw, (int)tt);
+      reduce_half(0u);
+      static_for<0, P>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        h[q] = mul_w<q, 2 * P, T>((xr[q] * w[q]) * rot);
+      });
+      prefetch();
+      FFT::run(h, lds, tw, (int)tt);
+      reduce_half(1u);
+      if (A.amax_value_only) bi = 0;
+      amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+      continue;
+    }
     Cx<V> v[P];                   // packed: both halves; unpacked: the even-bin half
     Cx<T> vo[PACKED ? 1 : P];     // unpacked: the odd-bin half
     static_for<0, P>([&](auto qc) {
@@ -365,23 +424,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         }
       }
     });
-    const long long s2 = s + gridDim.x;
-    if (s2 < A.n_batch) {  // prefetch the next FID while this one is transformed
-      const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
-      if (nin == NT * P && pl == 0u) {
-        // exactly half full (the 2x zero fill): every slot holds a sample, no clamp -- scalar row base +
-        // compile-time slot offset + one 32-bit lane offset, no per-load vector address arithmetic
-        const unsigned lane_off = tt * CB;  // 32-bit byte offset: lets the load use SGPR base + VGPR offset
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-          const char* rq = reinterpret_cast<const char*>(row + NT * q);
-          xr[q] = *reinterpret_cast<const Cx<T>*>(rq + lane_off);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
-      }
-    }
+    prefetch();
 
     FFT::run(v, lds, tw, (int)tt);
     if constexpr (!PACKED) FFT::run(vo, lds, tw, (int)tt);
