@@ -19,3 +19,9 @@ for rep in range(3):
     t2 = time.perf_counter()
     print(f"rep {rep}: {nv} spectra  upload+pipeline {1e3*(t1-t0):.1f} ms, download {1e3*(t2-t1):.1f} ms -> "
           f"{nv/(t2-t0)/1e6:.3f} M spectra/s  ({(x.nbytes+out.nbytes)/(t2-t0)/1e9:.1f} GB/s over the host link), p0={spec.attrs['phase_p0']:.4f}")
+# large-result download check: chunked pinned path == plain copy
+from xmris_amd import device as dev
+y = spec.data
+ref = y.cpu().numpy()
+t0 = time.perf_counter(); got = dev.to_host(y); t1 = time.perf_counter()
+print("to_host equal:", np.array_equal(ref, got), f"{got.nbytes/(t1-t0)/1e9:.1f} GB/s")

@@ -68,6 +68,60 @@ def to_device(a, device="cuda", dtype=None):
     return t.to(device)
 
 
+_HOST_STAGE = {}  # device index -> (pinned staging tensors, copy stream, worker pool)
+_HOST_STAGE_BUFS = 4
+
+
+def to_host(x, chunk_bytes: int = 32 << 20):
+    """Device tensor -> host ndarray.  Large results go through a few pinned staging buffers on a side stream:
+    the DMA of the next chunks overlaps the host memcpys (worker threads; first-touch page faults of the fresh
+    result dominate them) of the previous ones, instead of the runtime's own pageable path (measured 6.9 GB/s
+    for a 1 GiB result)."""
+    torch = _torch()
+    x = x.detach()
+    nbytes = x.numel() * x.element_size()
+    if not x.is_cuda or nbytes < 4 * chunk_bytes:
+        return x.cpu().numpy()
+    from concurrent.futures import ThreadPoolExecutor
+
+    x = x.contiguous()
+    dev_idx = x.device.index or 0
+    if dev_idx not in _HOST_STAGE:
+        _HOST_STAGE[dev_idx] = ([torch.empty(chunk_bytes, dtype=torch.uint8, pin_memory=True)
+                                 for _ in range(_HOST_STAGE_BUFS)],
+                                torch.cuda.Stream(device=x.device), ThreadPoolExecutor(max_workers=_HOST_STAGE_BUFS))
+    stage, side, pool = _HOST_STAGE[dev_idx]
+    np_dtype = {torch.complex64: np.complex64, torch.complex128: np.complex128, torch.float32: np.float32,
+                torch.float64: np.float64}.get(x.dtype)
+    if np_dtype is None or chunk_bytes != stage[0].numel():
+        return x.cpu().numpy()
+    out = np.empty(tuple(x.shape), dtype=np_dtype)
+    dst = out.reshape(-1).view(np.uint8)
+    src = (torch.view_as_real(x) if x.is_complex() else x).reshape(-1).view(torch.uint8)
+    stage_np = [b.numpy() for b in stage]
+    side.wait_stream(torch.cuda.current_stream(x.device))  # the producer kernels
+    pending = [None] * len(stage)
+
+    def drain(ev, lo, n, k):
+        ev.synchronize()
+        np.copyto(dst[lo:lo + n], stage_np[k][:n])
+
+    for i, lo in enumerate(range(0, nbytes, chunk_bytes)):
+        k, n = i % len(stage), min(chunk_bytes, nbytes - lo)
+        if pending[k] is not None:
+            pending[k].result()  # the staging buffer is free again
+        with torch.cuda.stream(side):
+            stage[k][:n].copy_(src[lo:lo + n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pending[k] = pool.submit(drain, ev, lo, n, k)
+    for f in pending:
+        if f is not None:
+            f.result()
+    x.record_stream(side)
+    return out
+
+
 def _rows(x, axis):
     """Move `axis` last and flatten the rest -> ([n_batch, n] contiguous, restore(y, n_new))."""
     nd = x.dim()

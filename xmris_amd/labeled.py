@@ -99,7 +99,9 @@ class LabeledArray:
     def values(self) -> np.ndarray:
         """Host ndarray (copies device-resident data over PCIe)."""
         if _is_tensor(self.data):
-            return self.data.detach().cpu().numpy()
+            from . import device as _dev
+
+            return _dev.to_host(self.data)
         return self.data
 
     def __array__(self, dtype=None, copy=None):

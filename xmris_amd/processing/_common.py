@@ -29,7 +29,7 @@ def maybe_real(x, was_real: bool):
 
 def to_host(x) -> np.ndarray:
     """Device tensor (or ndarray) -> host ndarray."""
-    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    return dev.to_host(x) if hasattr(x, "detach") else np.asarray(x)
 
 
 def binary_op_name(da: LabeledArray, dim: str):
