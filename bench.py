@@ -134,11 +134,6 @@ def main():
     freq = np.roll(np.fft.fftfreq(N, d=tt[1] - tt[0]), N // 2)
 
     out = torch.empty((nv, N), dtype=cdtype, device=device)
-    # two sets of pre-pass outputs: step i+1's pre-pass is queued while the host solves step i
-    absmax2 = [torch.empty(nv, dtype=rdtype, device=device) for _ in range(2)]
-    argidx = [torch.empty(nv, dtype=torch.int32, device=device) for _ in range(2)]
-    n_ev = max(args.steps, args.warmup, 1) + 1
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for k in ("pre0", "pre1", "main0", "main1")}
     times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": [], "gen_ms": [], "polish_ms": [], "table_ms": [], "period_ms": []}
     last = {}
 
@@ -146,73 +141,48 @@ def main():
     assert np.array_equal(plan.freq, freq)
     ddev = "cpu"
     overlap = not args.no_overlap
-    sel = [None, None]
 
-    def prepass(i):
-        b = i & 1
-        ev["pre0"][i].record()
-        dev.pipeline_fused(x, N, 0, window=plan.window, want_out=False, want_argmax=True, absmax2=absmax2[b],
-                           argidx=argidx[b], argmax_value_only=True)
-        ev["pre1"][i].record()
-        # selection stage queued right behind it (device-side arg-max -> fp64 slice -> pinned host copies)
-        sel[b] = pipeline.Selection(x, plan, absmax2[b], argidx[b], index_from_slice=True)
+    # O(1) per dataset: (max, global flat index) per rank -> the winner on every rank; (p0, p1) from its owner
+    def exchange(amax, gflat):
+        if shm is not None:
+            owner, gwin, _ = shm.exchange_argmax(amax, gflat)
+        else:
+            owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev, group=host_group)
+        return owner == rank, gwin, owner
+
+    def broadcast(values, owner):
+        if shm is not None:
+            return shm.broadcast_params(values, owner)
+        return sharding.broadcast_params(values, owner, dist, ddev, group=host_group)
 
     def run_steps(n_steps, record):
-        """n_steps complete passes of the hot path.  Datasets are independent, so with `overlap` the
-        device runs the pre-pass of dataset i+1 (and the main pass of dataset i-1) while the host searches
-        (p0, p1) for dataset i; every step still does all of its own work inside this call (no pre-pass is
-        left over or reused).  NB: `out` is rewritten by every step (same synthetic dataset each time)."""
-        prepass(0)
-        for i in range(n_steps):
-            b = i & 1
-            t0 = time.perf_counter()
-            state = {}
-
-            def exchange(amax, gflat):  # O(1): (max, global flat index) per rank -> the winner, on every rank
-                if shm is not None:
-                    owner, gwin, _ = shm.exchange_argmax(amax, gflat)
-                else:
-                    owner, gwin, _ = sharding.exchange_argmax(amax, gflat, dist, ddev, group=host_group)
-                state["owner"] = owner
-                state["t_x1"] = time.perf_counter()
-                return owner == rank, gwin
-
-            def queue_next():
-                if overlap and i + 1 < n_steps:
-                    prepass(i + 1)
-
-            res, mine = pipeline.select_and_solve(x, plan, absmax2[b], argidx[b], exchange=exchange,
-                                                  rank_offset_rows=rank * nv, on_host_phase=queue_next,
-                                                  selection=sel[b])
-            if shm is not None:
-                p0, p1 = shm.broadcast_params([res.p0, res.p1], state["owner"])
-            else:
-                p0, p1 = sharding.broadcast_params([res.p0, res.p1], state["owner"], dist, ddev, group=host_group)
-            t2 = time.perf_counter()
-            ph = pipeline.upload_phase_table(plan, x, p0, p1, res.pivot)
-            t3 = time.perf_counter()
-            ev["main0"][i].record()
-            dev.pipeline_fused(x, N, 0, window=plan.window, phase_table=ph, out=out)
-            ev["main1"][i].record()
-            if not overlap and i + 1 < n_steps:
-                prepass(i + 1)
-            last.update(p0=p0, p1=p1, pivot=res.pivot, flat=res.flat_index, owner=state["owner"])
-            if mine:
-                last["nfev"] = res.nfev
-            if record:
-                times["exchange_ms"].append((state["t_x1"] - t0) * 1e3)
-                times["solve_ms"].append((t2 - state["t_x1"]) * 1e3)
-                times["table_ms"].append((t3 - t2) * 1e3)
-                if mine:
-                    times["gen_ms"].append(res.timing.get("generations_ms", 0.0))
-                    times["polish_ms"].append(res.timing.get("polish_ms", 0.0))
+        """n_steps complete passes of the hot path = xmris_amd.pipeline.run_stream over n_steps independent
+        datasets (the library's software-pipelined executor: with `overlap` the device runs the pre-pass of
+        dataset i+1 and the main pass of dataset i-1 while the host searches (p0, p1) for dataset i; every
+        step does all of its own work inside this call, nothing is left over or reused).  NB: the same
+        synthetic dataset and output buffer are passed for every step."""
+        trace = []
+        results = pipeline.run_stream([x] * n_steps, [out] * n_steps, plan, exchange=exchange if world > 1 else None,
+                                      broadcast=broadcast if world > 1 else None, rank_offset_rows=rank * nv,
+                                      overlap=overlap, trace=trace)
+        res = results[-1]
+        last.update(p0=res.p0, p1=res.p1, pivot=res.pivot, flat=res.flat_index, owner=res.owner)
+        for r in results:
+            if r.mine:
+                last["nfev"] = r.nfev
         if record:  # kernel durations are read after the loop so that no step waits for its own main pass
             torch.cuda.synchronize()
-            for i in range(n_steps):
-                times["pre_ms"].append(ev["pre0"][i].elapsed_time(ev["pre1"][i]))
-                times["main_ms"].append(ev["main0"][i].elapsed_time(ev["main1"][i]))
+            for i, (e, r) in enumerate(zip(trace, results)):
+                times["exchange_ms"].append((e["t_exchanged"] - e["t_start"]) * 1e3)
+                times["solve_ms"].append((e["t_solved"] - e["t_exchanged"]) * 1e3)
+                times["table_ms"].append((e["t_table"] - e["t_solved"]) * 1e3)
+                if r.mine:
+                    times["gen_ms"].append(r.timing.get("generations_ms", 0.0))
+                    times["polish_ms"].append(r.timing.get("polish_ms", 0.0))
+                times["pre_ms"].append(e["pre0"].elapsed_time(e["pre1"]))
+                times["main_ms"].append(e["main0"].elapsed_time(e["main1"]))
                 if i + 1 < n_steps:  # device-side period: start of main pass i -> start of main pass i+1
-                    times["period_ms"].append(ev["main0"][i].elapsed_time(ev["main0"][i + 1]))
+                    times["period_ms"].append(e["main0"].elapsed_time(trace[i + 1]["main0"]))
 
     def barrier():
         if dist is not None:

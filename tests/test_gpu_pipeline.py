@@ -136,3 +136,33 @@ def test_full_size_properties(mods, oracle):
     xw = x * plan.window[:nt][None, :]
     e_in = (xw.real.double() ** 2 + xw.imag.double() ** 2).sum(dim=1)
     assert float(((e_out - e_in).abs() / e_in).max()) < 1e-5
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_run_stream_equals_one_dataset_at_a_time(mods, overlap):
+    """The software-pipelined executor (what bench.py times) must give, dataset by dataset, exactly what the
+    one-shot `run` gives: same winner, same (p0, p1), same phased spectra -- with five DIFFERENT datasets in
+    flight, so a mixed-up double buffer (pre-pass outputs, pinned selection buffers, phase tables) shows."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 96, 512, 1024
+    sets, t = [], None
+    for k in range(5):
+        x, t = _three_peak(nv, nt, 2e-4, seed=100 + k)
+        x[nv // 3] *= 0.2             # move the winner: a different row (and scale) per dataset
+        x[(7 * k + 3) % nv] *= 3.0 + k
+        sets.append(dev.to_device(x.astype(np.complex64)))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=torch.complex64, device="cuda") for _ in sets]
+    trace = []
+    results = pipe.run_stream(sets, outs, plan, overlap=overlap, trace=trace)
+    torch.cuda.synchronize()
+    assert len(results) == len(trace) == 5
+    for k, (xd, od, r) in enumerate(zip(sets, outs, results)):
+        ref_out, ref_res, _ = pipe.run(xd, t, target, 5.0)
+        assert (r.flat_index, r.target_idx, r.pivot) == (ref_res.flat_index, ref_res.target_idx, ref_res.pivot), k
+        assert r.flat_index // target == (7 * k + 3) % nv
+        assert (r.p0, r.p1) == (ref_res.p0, ref_res.p1), k
+        assert torch.equal(od, ref_out), k
+        assert trace[k]["pre0"].elapsed_time(trace[k]["main1"]) > 0

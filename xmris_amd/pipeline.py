@@ -81,6 +81,8 @@ class AutophaseResult:
     nfev: int = 0
     fun: float = float("nan")
     timing: dict = field(default_factory=dict)
+    owner: int = 0      # rank that owns the winning spectrum (run_stream)
+    mine: bool = True   # ... and whether that is this rank
 
 
 class Selection:
@@ -204,6 +206,104 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     ph = upload_phase_table(plan, x2, res.p0, res.p1, res.pivot)
     main = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, phase_table=ph, out=out)
     return main.out, res, plan
+
+
+def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=None, rank_offset_rows: int = 0,
+               overlap: bool = True, method: str = "acme", peak_width=100, target_coord=None, p0_only: bool = False,
+               trace: list | None = None):
+    """The fused hot path over a SEQUENCE of independent datasets of one shape, software-pipelined.
+
+    ``inputs[i]`` ([n_batch, n_in] complex rows in HBM) is transformed into ``outputs[i]`` ([n_batch, n_out]);
+    the lists may repeat tensors.  Per dataset the device does a pre-pass (per-spectrum max |X|^2), the
+    selection stage (`Selection`) and the main pass; the host does the O(1) exchange, the (p0, p1) search on
+    the winning spectrum and the phase table.  With `overlap` the pre-pass + selection of dataset i+1 is queued
+    before the host starts searching for dataset i, so the device works on dataset i+1 (and on the main pass
+    of dataset i-1) while the host searches -- every dataset still gets all of its own work, nothing is
+    reused across datasets.
+
+    Multi-device: `exchange(max_abs, global_flat) -> (owner_rank_is_me, winning_global_flat, owner)` merges
+    the per-rank winners and `broadcast(values, owner) -> values` hands the owner's (p0, p1) to every rank
+    (`xmris_amd.sharding`); `rank_offset_rows` = first global row of this rank's shard.
+
+    `trace`, if given, receives one dict per dataset: host timestamps (`t_start`, `t_exchanged`, `t_solved`,
+    `t_table`) and torch events around the two kernels (`pre0`, `pre1`, `main0`, `main1`).
+    Returns the list of AutophaseResult (p0, p1 filled on every rank)."""
+    import time
+
+    import torch
+
+    n_sets = len(inputs)
+    if n_sets != len(outputs):
+        raise ValueError("inputs and outputs must have the same length")
+    if n_sets == 0:
+        return []
+    n = plan.n_out
+    x0 = inputs[0]
+    rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
+    bufs = plan.extra.get(("stream_bufs", x0.shape[0], str(rd)))
+    if bufs is None:  # two sets of pre-pass outputs: dataset i+1's pre-pass runs while dataset i is being solved
+        bufs = plan.extra[("stream_bufs", x0.shape[0], str(rd))] = (
+            [torch.empty(x0.shape[0], dtype=rd, device=x0.device) for _ in range(2)],
+            [torch.empty(x0.shape[0], dtype=torch.int32, device=x0.device) for _ in range(2)])
+    absmax2, argidx = bufs
+    sel = [None, None]
+    events = [dict() for _ in range(n_sets)]
+
+    def prepass(i):
+        b = i & 1
+        ev = events[i]
+        if trace is not None:
+            ev["pre0"], ev["pre1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev["pre0"].record()
+        dev.pipeline_fused(inputs[i], n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True,
+                           absmax2=absmax2[b], argidx=argidx[b], argmax_value_only=True)
+        if trace is not None:
+            ev["pre1"].record()
+        # selection stage queued right behind it (device-side arg-max -> fp64 slice -> pinned host memory)
+        sel[b] = Selection(inputs[i], plan, absmax2[b], argidx[b], index_from_slice=True)
+
+    results = []
+    prepass(0)
+    for i in range(n_sets):
+        b = i & 1
+        ev = events[i]
+        ev["t_start"] = time.perf_counter()
+        owner_box = [0]
+
+        def merged(amax, gflat):
+            if exchange is None:
+                ev["t_exchanged"] = time.perf_counter()
+                return True, gflat
+            mine, gwin, owner = exchange(amax, gflat)
+            owner_box[0] = owner
+            ev["t_exchanged"] = time.perf_counter()
+            return mine, gwin
+
+        def queue_next():
+            if overlap and i + 1 < n_sets:
+                prepass(i + 1)
+
+        res, mine = select_and_solve(inputs[i], plan, absmax2[b], argidx[b], method, peak_width, target_coord,
+                                     p0_only, exchange=merged, rank_offset_rows=rank_offset_rows,
+                                     on_host_phase=queue_next, selection=sel[b])
+        if broadcast is not None:
+            res.p0, res.p1 = broadcast([res.p0, res.p1], owner_box[0])
+        res.owner, res.mine = owner_box[0], mine
+        ev["t_solved"] = time.perf_counter()
+        ph = upload_phase_table(plan, inputs[i], res.p0, res.p1, res.pivot)
+        ev["t_table"] = time.perf_counter()
+        if trace is not None:
+            ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev["main0"].record()
+        dev.pipeline_fused(inputs[i], n, plan.pad_left, window=plan.window, phase_table=ph, out=outputs[i])
+        if trace is not None:
+            ev["main1"].record()
+        if not overlap and i + 1 < n_sets:
+            prepass(i + 1)
+        results.append(res)
+        if trace is not None:
+            trace.append(ev)
+    return results
 
 
 def upload_phase_table(plan: PipelinePlan, like, p0: float, p1: float, pivot: float):
