@@ -80,6 +80,27 @@ def index_width_of(coords: np.ndarray, peak_width: float) -> int:
     return max(1, int(round((peak_width / 2.0) / step)))
 
 
+def default_threads() -> int:
+    """Team size for the native objective: at most 16, at most this process's share of the CPUs it may use
+    (scheduler affinity and the cgroup v2 quota, divided by the ranks torchrun started on this node) -- spinning
+    workers beyond the quota are throttled by the kernel and slow the search down instead of speeding it up."""
+    import os
+
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(1, min(16, cpus // local_world))
+
+
 class NativeObjective:
     """The three objectives evaluated by libxmris_hip.so's host solver (vectorised C++, fp64)."""
 
@@ -93,6 +114,7 @@ class NativeObjective:
                                              METHODS.index(method), int(target_idx), int(index_width))
         if not self._h:
             raise ValueError("xm_solver_create rejected the slice (needs n >= 2 and a valid target index)")
+        self.set_threads(default_threads())
 
     def __call__(self, x):
         xx = np.ascontiguousarray(x, dtype=np.float64)
