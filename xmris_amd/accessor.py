@@ -13,7 +13,7 @@ from .config import DIMS
 from .processing.fid import apodize_exp, apodize_lg, to_fid, to_spectrum, zero_fill
 from .processing.fourier import fft, fftc, fftshift, ifft, ifftc, ifftshift
 from .processing.phasing import autophase, phase
-from .utils import _check_dims  # noqa: F401  (the reference re-exports it from its accessor module)
+from .dims import _check_dims  # noqa: F401  (the reference re-exports it from its accessor module)
 
 
 class XmrisFourierMixin:

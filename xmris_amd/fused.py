@@ -14,7 +14,7 @@ from . import pipeline as pl
 from .config import ATTRS, COORDS, DIMS
 from .labeled import Coordinate, LabeledArray, as_labeled, like_input
 from .processing._common import device_data
-from .utils import _check_dims, term_attrs
+from .dims import _check_dims, term_attrs
 
 
 def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,

@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import device as dev
 from ..config import ATTRS, DIMS
-from ..utils import _check_dims
+from ..dims import _check_dims
 from ._common import as_labeled, like_input
 
 

@@ -12,7 +12,7 @@ import numpy as np
 
 from .. import device as dev
 from ..config import ATTRS, COORDS, DIMS
-from ..utils import _check_dims, term_attrs
+from ..dims import _check_dims, term_attrs
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
                       maybe_real)
 from .fourier import fft, fftshift, ifft, ifftshift

@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import device as dev
 from ..config import COORDS, DIMS
-from ..utils import _check_dims, term_attrs
+from ..dims import _check_dims, term_attrs
 from ._common import Coordinate, LabeledArray, as_labeled, device_data, like_input, maybe_real
 
 

@@ -16,7 +16,7 @@ import numpy as np
 from .. import autophase_solver as aps
 from .. import device as dev
 from ..config import ATTRS, DIMS
-from ..utils import _check_dims
+from ..dims import _check_dims
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
                       to_host)
 
