@@ -504,6 +504,9 @@ constexpr int fft2_waves() {
   const long lds = (long)BlockFFT<xm_f2, PL>::lds_elems() * (long)sizeof(Cx<xm_f2>);
   const int wg = 160 * 1024 / lds >= 2 ? 2 : 1;
   int w = wg * PL::NT / 256;
+  // 512 threads x 8 points x two packed spectra need ~150 VGPRs: one 512-thread workgroup per CU without spills
+  // beats two with ~40 spilled registers (4096-point FFT seam 4.3 -> 4.8 TB/s, fused main pass 3.6 -> 5.1 TB/s)
+  if (PL::NT == 512 && w > 2) w = 2;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
