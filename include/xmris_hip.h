@@ -8,7 +8,9 @@
  * attrs, validation, exceptions) stays in the Python host layer (`xmris_amd/`).
  *
  * Conventions
- *  - Plain C types only.  All array pointers are DEVICE pointers owned by the caller; the
+ *  - Plain C types only.  All array pointers are DEVICE-ACCESSIBLE pointers owned by the caller (device
+ *    memory; small outputs may also live in hipHostMalloc'd host memory, which the selection stage uses
+ *    to hand (max, flat index, winning spectrum) to the host without memcpy nodes); the
  *    library never frees or retains them.  `stream` is a hipStream_t passed as void* (NULL =
  *    the default stream).  Calls are asynchronous on that stream; nothing synchronises.
  *  - Layout: `n_batch` spectra, C-contiguous, FID / frequency axis last, interleaved complex
@@ -86,7 +88,7 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
 
 /* A6  global arg-max  (phasing.py:229  np.argmax(np.abs(values)), first maximum in C order).
  * Reduces the per-spectrum pairs: out_max2[0] = max_b absmax2[b], out_flat[0] = b*n + argidx[b]
- * of the first such b.  Both outputs are device scalars. */
+ * of the first such b.  Both outputs are device-accessible scalars. */
 int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch, int n, void* out_max2,
                      int64_t* out_flat, int dtype, void* stream);
 
