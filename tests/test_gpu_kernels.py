@@ -230,3 +230,17 @@ def test_unsupported_length_raises(dev):
         dev.fft(x, 1)
     with pytest.raises(RuntimeError):
         dev.fft(x.cpu(), 1)  # no CPU path
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "float64"])
+def test_to_host_staged_download_is_exact(dev, dtype):
+    """Large results leave HBM through pinned staging buffers + worker-thread memcpys (device.to_host): the bytes
+    must be the ones a plain copy delivers, including a ragged last chunk and a non-contiguous source."""
+    import torch
+
+    n = (5 * (32 << 20) + 12345) // 8  # five and a bit staging chunks of complex64
+    x = torch.randn(n, 2, device="cuda")
+    x = torch.view_as_complex(x) if dtype == "complex64" else x.double().reshape(-1)
+    assert np.array_equal(dev.to_host(x), x.cpu().numpy())
+    y = x[: (x.numel() // 6) * 6].reshape(-1, 6)[:, ::2]  # strided view
+    assert np.array_equal(dev.to_host(y), y.cpu().numpy())

@@ -70,6 +70,7 @@ def to_device(a, device="cuda", dtype=None):
 
 _HOST_STAGE = {}  # device index -> (pinned staging tensors, copy stream, worker pool)
 _HOST_STAGE_BUFS = 4
+_HOST_STAGE_LOCK = __import__("threading").Lock()  # one large download at a time shares the staging buffers
 
 
 def to_host(x, chunk_bytes: int = 32 << 20):
@@ -82,9 +83,15 @@ def to_host(x, chunk_bytes: int = 32 << 20):
     nbytes = x.numel() * x.element_size()
     if not x.is_cuda or nbytes < 4 * chunk_bytes:
         return x.cpu().numpy()
+    with _HOST_STAGE_LOCK:
+        return _to_host_staged(x.contiguous(), chunk_bytes)
+
+
+def _to_host_staged(x, chunk_bytes: int):
+    torch = _torch()
     from concurrent.futures import ThreadPoolExecutor
 
-    x = x.contiguous()
+    nbytes = x.numel() * x.element_size()
     dev_idx = x.device.index or 0
     if dev_idx not in _HOST_STAGE:
         _HOST_STAGE[dev_idx] = ([torch.empty(chunk_bytes, dtype=torch.uint8, pin_memory=True)
