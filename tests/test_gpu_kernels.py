@@ -244,3 +244,23 @@ def test_to_host_staged_download_is_exact(dev, dtype):
     assert np.array_equal(dev.to_host(x), x.cpu().numpy())
     y = x[: (x.numel() // 6) * 6].reshape(-1, 6)[:, ::2]  # strided view
     assert np.array_equal(dev.to_host(y), y.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n_in,n_out", [(4096, 8192), (512, 1024), (1000, 4096), (1536, 1536), (1972, 1972)])
+def test_fused_pipeline_without_window_or_phase(dev, oracle, n_in, n_out, dtype):
+    """`window == NULL` / `phase_table == NULL` through the C ABI: plain zero-fill + ortho FFT + fftshift, with
+    and without the arg-max outputs (the >= 2x kernels fold the window into per-thread constants: the
+    no-window case must still scale by 1/sqrt(n) only)."""
+    x = _rand((6, n_in), dtype, seed=n_in)
+    spec = oracle.to_spectrum_values(np.pad(x.astype(np.complex128), [(0, 0), (0, n_out - n_in)]), 1)
+    xd = dev.to_device(x)
+    tol = TIGHT[dtype] * (4 if n_out == 1972 else 1)
+    pre = dev.pipeline_fused(xd, n_out, 0, want_out=False, want_argmax=True)
+    np.testing.assert_array_equal(pre.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
+    np.testing.assert_allclose(np.sqrt(pre.absmax2.cpu().numpy().astype(np.float64)), np.abs(spec).max(axis=1),
+                               rtol=20 * tol)
+    both = dev.pipeline_fused(xd, n_out, 0, want_argmax=True)
+    assert _relerr(both.out.cpu().numpy(), spec) < tol
+    np.testing.assert_array_equal(both.argidx.cpu().numpy(), pre.argidx.cpu().numpy())
+    assert _relerr(dev.pipeline_fused(xd, n_out, 0).out.cpu().numpy(), spec) < tol

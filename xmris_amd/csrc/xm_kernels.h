@@ -225,17 +225,25 @@ XM_DEV CxPair<double> buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned
   c.b = buf_load(r, voff + 16u, soff, (Cx<double>*)nullptr);
   return c;
 }
-XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<float> v) {
+// VMEM store-data hazard.  A buffer store of more than 64 bits reads its data VGPRs over several cycles; a VALU
+// instruction issued right behind it that overwrites one of them corrupts what is stored.  LLVM's hazard
+// recogniser inserts the wait state only for MUBUF stores WITHOUT an SGPR soffset (the documented SI-era rule),
+// but gfx950 shows the hazard with an SGPR soffset too: in the write-only mode of k_zf2 -- nothing between one
+// store and the next output's arithmetic -- dword 1 of lanes 12..15 of every 16-lane group carried the NEXT
+// butterfly's value.  Hence these wide stores never use an SGPR soffset: the wave-uniform part of the address
+// goes into the buffer descriptor's base (scalar ALU) and `soffset` is the literal 0, which keeps the
+// compiler's own hazard handling in charge.
+XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, CxPair<float> v) {
   xm_u4 u;
   __builtin_memcpy(&u, &v, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
 }
-XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, CxPair<double> v) {
+XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, CxPair<double> v) {
   xm_u4 u;
   __builtin_memcpy(&u, &v.a, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
   __builtin_memcpy(&u, &v.b, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff + 16u, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff + 16u, 0, 0);
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
@@ -470,11 +478,13 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
       amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
     }
     if constexpr (WRITE) {
-      const __amdgpu_buffer_rsrc_t rout = xm_rsrc(A.out + s * (long long)N, N * CB);
+      Cx<T>* __restrict__ orow = A.out + s * (long long)N;
       const __amdgpu_buffer_rsrc_t rph = xm_rsrc(A.phase, PHASE ? N * CB : 0u);
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
+        // this butterfly's 2*NT contiguous outputs: descriptor base = row + base (see buf_store)
+        const __amdgpu_buffer_rsrc_t rout = xm_rsrc(orow + base, 2u * NT * CB);
         Cx<T> xe = even(q);
         Cx<T> xo = odd(q);
         if constexpr (PHASE) {
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         CxPair<T> o;
         o.a = xe;
         o.b = xo;
-        buf_store(rout, t2 * CB, base * CB, o);
+        buf_store(rout, t2 * CB, o);
       }
     }
   }
