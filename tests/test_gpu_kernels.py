@@ -264,3 +264,43 @@ def test_fused_pipeline_without_window_or_phase(dev, oracle, n_in, n_out, dtype)
     assert _relerr(both.out.cpu().numpy(), spec) < tol
     np.testing.assert_array_equal(both.argidx.cpu().numpy(), pre.argidx.cpu().numpy())
     assert _relerr(dev.pipeline_fused(xd, n_out, 0).out.cpu().numpy(), spec) < tol
+
+
+MODE_SHAPES = [(4096, 8192), (1024, 2048), (2048, 2048), (3072, 3072), (700, 1000), (100, 128), (3000, 3001)]
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n_in,n_out", MODE_SHAPES)
+def test_every_output_combination_of_the_fused_entry_point(dev, oracle, n_in, n_out, dtype):
+    """xm_pipeline_fused with every combination of {window, phase table, spectrum output, arg-max outputs}: each
+    combination instantiates a different kernel mode (and a different instruction schedule around the stores), so
+    each is checked on its own -- for every kernel family (>= 2x zero fill, pair / scalar persistent FFT, chirp-z
+    persistent and one-spectrum, small-n generic)."""
+    import itertools
+
+    import torch
+
+    nb = 5
+    x = _rand((nb, n_in), dtype, seed=7 * n_in + n_out)
+    xpad = np.pad(x.astype(np.complex128), [(0, 0), (0, n_out - n_in)])
+    w = oracle.exp_window(np.arange(n_out) * 2e-4, 3.0)
+    freq = np.roll(np.fft.fftfreq(n_out, d=2e-4), n_out // 2)
+    ph = np.exp(1j * oracle.phase_array(freq, -17.0, 250.0, float(freq[n_out // 5])))
+    xd = dev.to_device(x)
+    rd = torch.float32 if dtype == "complex64" else torch.float64
+    wd = torch.from_numpy(w).to("cuda", rd)
+    phd = torch.from_numpy(ph).to("cuda", xd.dtype)
+    tol = TIGHT[dtype] * (4 if n_out in (1000, 3001) else 1)
+    for use_w, use_ph, want_out, want_amax in itertools.product((False, True), repeat=4):
+        if not want_out and (use_ph or not want_amax):
+            continue  # nothing to produce / phase without an output
+        spec = oracle.to_spectrum_values(xpad * (w if use_w else 1.0), 1)
+        r = dev.pipeline_fused(xd, n_out, 0, window=wd if use_w else None, phase_table=phd if use_ph else None,
+                               want_out=want_out, want_argmax=want_amax)
+        tag = (use_w, use_ph, want_out, want_amax)
+        if want_out:
+            assert _relerr(r.out.cpu().numpy(), spec * (ph if use_ph else 1.0)) < tol, tag
+        if want_amax:  # the arg-max is taken BEFORE the phase multiply (|X e^{i phi}| = |X|)
+            np.testing.assert_array_equal(r.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1), err_msg=str(tag))
+            np.testing.assert_allclose(np.sqrt(r.absmax2.cpu().numpy().astype(np.float64)), np.abs(spec).max(axis=1),
+                                       rtol=20 * tol, err_msg=str(tag))
