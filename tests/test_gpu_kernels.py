@@ -304,3 +304,17 @@ def test_every_output_combination_of_the_fused_entry_point(dev, oracle, n_in, n_
             np.testing.assert_array_equal(r.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1), err_msg=str(tag))
             np.testing.assert_allclose(np.sqrt(r.absmax2.cpu().numpy().astype(np.float64)), np.abs(spec).max(axis=1),
                                        rtol=20 * tol, err_msg=str(tag))
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n", [64, 512, 1536, 2048, 4096, 5120, 8192, 1000, 1972, 4093])
+def test_single_row_and_two_row_transforms(dev, oracle, n, dtype):
+    """n_batch = 1 takes the one-spectrum kernels (the pair / persistent kernels need two rows), n_batch = 2 is
+    the smallest input of the persistent ones: both must match numpy, with the rolls folded in."""
+    for nb in (1, 2):
+        x = _rand((nb, n), dtype, seed=n + nb)
+        xd = dev.to_device(x)
+        tol = TIGHT[dtype] * (4 if n in (1000, 1972, 4093) else 1)
+        assert _relerr(dev.fft(xd, 1, shift_out=True).cpu().numpy(), oracle.to_spectrum_values(x.astype(np.complex128), 1)) < tol
+        back = dev.fft(dev.fft(xd, 1, shift_out=True), 1, inverse=True, shift_in=True).cpu().numpy()
+        assert _relerr(back, x.astype(np.complex128)) < 2 * tol
