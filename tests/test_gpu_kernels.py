@@ -318,3 +318,33 @@ def test_single_row_and_two_row_transforms(dev, oracle, n, dtype):
         assert _relerr(dev.fft(xd, 1, shift_out=True).cpu().numpy(), oracle.to_spectrum_values(x.astype(np.complex128), 1)) < tol
         back = dev.fft(dev.fft(xd, 1, shift_out=True), 1, inverse=True, shift_in=True).cpu().numpy()
         assert _relerr(back, x.astype(np.complex128)) < 2 * tol
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n_in,n_out", [(4096, 8192), (2048, 2048), (1536, 1536), (1972, 1972), (100, 128)])
+def test_strided_input_rows_through_the_c_abi(dev, oracle, n_in, n_out, dtype):
+    """`in_row_stride` > n_in: the rows of the input are slices of wider rows (what the Bruker group-delay cut
+    hands over); every kernel family must honour the stride in its first load AND in its prefetch."""
+    import torch
+
+    from xmris_amd import _lib
+
+    nb, stride = 9, n_in + 24
+    wide = _rand((nb, stride), dtype, seed=n_in)
+    x = wide[:, 5:5 + n_in]
+    spec = oracle.to_spectrum_values(np.pad(x.astype(np.complex128), [(0, 0), (0, n_out - n_in)]), 1)
+    wd = dev.to_device(wide)
+    out = torch.empty((nb, n_out), dtype=wd.dtype, device="cuda")
+    am = torch.empty(nb, dtype=torch.float32 if dtype == "complex64" else torch.float64, device="cuda")
+    ai = torch.empty(nb, dtype=torch.int32, device="cuda")
+    code = _lib.XM_C64 if dtype == "complex64" else _lib.XM_C128
+    first = wd.data_ptr() + 5 * wd.element_size()
+    flags = _lib.XM_FFT_ORTHO | _lib.XM_FFT_SHIFT_OUT
+    _lib.call("xm_pipeline_fused", first, stride, out.data_ptr(), None, None, nb, n_in, n_out, 0, flags,
+              am.data_ptr(), ai.data_ptr(), code, torch.cuda.current_stream().cuda_stream)
+    tol = TIGHT[dtype] * (4 if n_out == 1972 else 1)
+    assert _relerr(out.cpu().numpy(), spec) < tol
+    np.testing.assert_array_equal(ai.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
+    _lib.call("xm_pipeline_fused", first, stride, None, None, None, nb, n_in, n_out, 0, flags,
+              am.data_ptr(), ai.data_ptr(), code, torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_array_equal(ai.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
