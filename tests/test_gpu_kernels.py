@@ -348,3 +348,22 @@ def test_strided_input_rows_through_the_c_abi(dev, oracle, n_in, n_out, dtype):
     _lib.call("xm_pipeline_fused", first, stride, None, None, None, nb, n_in, n_out, 0, flags,
               am.data_ptr(), ai.data_ptr(), code, torch.cuda.current_stream().cuda_stream)
     np.testing.assert_array_equal(ai.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
+
+
+@pytest.mark.parametrize("dtype,n_in,n_out", [("complex64", 4096, 8192), ("complex128", 4096, 8192),
+                                              ("complex64", 2048, 2048), ("complex128", 2048, 2048),
+                                              ("complex64", 1000, 1000), ("complex128", 1000, 1000)])
+def test_persistent_grid_boundaries(dev, oracle, dtype, n_in, n_out):
+    """Batch sizes around the persistent grids (256 / 512 resident workgroups, pairs of rows per workgroup):
+    one row fewer, exactly, one more, and an odd count a few grids long -- tail iterations, the prefetch guard
+    and the duplicated odd row of the pair kernels."""
+    import torch
+
+    rd = torch.float32 if dtype == "complex64" else torch.float64
+    for nb in (255, 256, 257, 511, 513, 1027):
+        x = _rand((nb, n_in), dtype, seed=nb)
+        spec = oracle.to_spectrum_values(np.pad(x.astype(np.complex128), [(0, 0), (0, n_out - n_in)]), 1)
+        r = dev.pipeline_fused(dev.to_device(x), n_out, 0, want_argmax=True)
+        tol = TIGHT[dtype] * (4 if n_out == 1000 else 1)
+        assert _relerr(r.out.cpu().numpy(), spec) < tol, nb
+        np.testing.assert_array_equal(r.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1), err_msg=str(nb))
