@@ -367,3 +367,22 @@ def test_persistent_grid_boundaries(dev, oracle, dtype, n_in, n_out):
         tol = TIGHT[dtype] * (4 if n_out == 1000 else 1)
         assert _relerr(r.out.cpu().numpy(), spec) < tol, nb
         np.testing.assert_array_equal(r.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1), err_msg=str(nb))
+
+
+def test_clear_cache_between_launches(dev, oracle):
+    """xm_clear_cache() frees the cached twiddle / chirp / half-rotation tables; the next launch rebuilds them.
+    (Queued work must have finished first: the tables are read by in-flight kernels.)"""
+    import torch
+
+    from xmris_amd import _lib
+
+    x = _rand((6, 1531), "complex64", seed=9)
+    z = _rand((6, 2048), "complex64", seed=10)
+    xd, zd = dev.to_device(x), dev.to_device(z)
+    a1 = dev.fft(xd, 1, shift_out=True).cpu().numpy()
+    b1 = dev.pipeline_fused(zd, 4096, 0).out.cpu().numpy()
+    torch.cuda.synchronize()
+    _lib.call("xm_clear_cache")
+    assert np.array_equal(dev.fft(xd, 1, shift_out=True).cpu().numpy(), a1)
+    assert np.array_equal(dev.pipeline_fused(zd, 4096, 0).out.cpu().numpy(), b1)
+    assert _relerr(a1, oracle.to_spectrum_values(x.astype(np.complex128), 1)) < 4 * TIGHT["complex64"]
