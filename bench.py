@@ -78,6 +78,9 @@ def main():
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --share-gpu) to exercise "
                          "the multi-rank code path on a single-GPU box; the driver uses the default (RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-speculate", action="store_true",
+                    help="classic schedule: arg-max pre-pass (an FFT of every FID) instead of the verified guess of the "
+                         "winning row from the FIDs' windowed L1 norms (pipeline.run_stream(speculate=...))")
     ap.add_argument("--exchange", choices=["shm", "gloo"], default="shm",
                     help="N > 1: the O(1) host exchange goes through a shared-memory page (one node) or gloo")
     args = ap.parse_args()
@@ -141,6 +144,8 @@ def main():
     assert np.array_equal(plan.freq, freq)
     ddev = "cpu"
     overlap = not args.no_overlap
+    speculate = not args.no_speculate
+    spec_stats = {}
 
     # O(1) per dataset: (max, global flat index) per rank -> the winner on every rank; (p0, p1) from its owner
     def exchange(amax, gflat):
@@ -164,7 +169,10 @@ def main():
         trace = []
         results = pipeline.run_stream([x] * n_steps, [out] * n_steps, plan, exchange=exchange if world > 1 else None,
                                       broadcast=broadcast if world > 1 else None, rank_offset_rows=rank * nv,
-                                      overlap=overlap, trace=trace)
+                                      overlap=overlap, trace=trace, speculate=speculate)
+        for r in results:
+            if speculate:
+                spec_stats[r.speculation] = spec_stats.get(r.speculation, 0) + (1 if record else 0)
         res = results[-1]
         last.update(p0=res.p0, p1=res.p1, pivot=res.pivot, flat=res.flat_index, owner=res.owner)
         for r in results:
@@ -228,16 +236,17 @@ def main():
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": (("k_zf2<float, FftPlan<4096,256,16,16,16>, 3>" if args.dtype == "c64" else
-                                        "k_zf2<double, FftPlan<4096,512,8,8,8,8>, 3>") if (nt, N) == (4096, 8192)
-                                       else "xm_pipeline_fused main pass") + " (zero-fill+window+FFT+fftshift+phase)",
+            "bound": "hbm", "kernel": ((f"k_zf2<float, FftPlan<4096,256,16,16,16>, {7 if speculate else 3}>" if args.dtype == "c64" else
+                                        f"k_zf2<double, FftPlan<4096,512,8,8,8,8>, {7 if speculate else 3}>")
+                                       if (nt, N) == (4096, 8192) else "xm_pipeline_fused main pass")
+                                      + " (zero-fill+window+FFT+fftshift+phase" + ("+per-row maxima)" if speculate else ")"),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None),
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01/pmc_main_kernel.txt",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
         },
         "breakdown_ms": {
-            "prepass_kernel": pre_ms, "main_kernel": main_ms,
+            ("guess_kernel_row_l1" if speculate else "prepass_kernel"): pre_ms, "main_kernel": main_ms,
             "argmax_reduce_and_exchange": float(np.mean(times["exchange_ms"])),
             "slice_de_solve_broadcast": float(np.mean(times["solve_ms"])),
             "solver_generations": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
@@ -249,8 +258,13 @@ def main():
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
         "autophase": {k: last.get(k) for k in ("p0", "p1", "pivot", "flat", "owner", "nfev")},
-        "schedule": ("pre-pass of step i+1 overlaps the host solve of step i (independent datasets)" if overlap
+        "schedule": (("guess pass (windowed L1 norms) of step i+1 overlaps the host solve of step i; the main pass "
+                      "returns the true per-row maxima and the guess is verified (repaired if wrong) before the next "
+                      "main pass" if speculate else
+                      "pre-pass of step i+1 overlaps the host solve of step i (independent datasets)") if overlap
                      else "strictly serial steps"),
+        "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0)}
+                        if speculate else {"enabled": False}),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

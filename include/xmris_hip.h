@@ -86,6 +86,15 @@ int xm_phase_apply(const void* in, void* out, const void* phase_table, int64_t n
 int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_t* argidx, int dtype,
                    void* stream);
 
+/* A6, speculative schedule: norm[b] = sum_j |in[b, j]| * |window[j + pad_left]| (window may be NULL), the windowed
+ * L1 norm of every FID.  sum|z| / sqrt(N) bounds every |X[k]| of the row and equals the peak of a single decaying
+ * resonance, so the row with the largest norm is the guess for the row through the global maximum
+ * (phasing.py:229) that lets the host search (p0, p1) BEFORE any spectrum exists; the fused main pass then
+ * returns the true per-row maxima, and a wrong guess is repaired (see xmris_amd/pipeline.py::run_stream).
+ * `norm`: n_batch reals of the storage precision. */
+int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int pad_left,
+              void* norm, int dtype, void* stream);
+
 /* A6  global arg-max  (phasing.py:229  np.argmax(np.abs(values)), first maximum in C order).
  * Reduces the per-spectrum pairs: out_max2[0] = max_b absmax2[b], out_flat[0] = b*n + argidx[b]
  * of the first such b.  Both outputs are device-accessible scalars. */

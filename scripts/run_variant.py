@@ -11,7 +11,7 @@ ph = torch.view_as_complex(torch.randn(N, 2, device="cuda"))
 out = torch.empty(nv, N, dtype=torch.complex64, device="cuda")
 am = torch.empty(nv, device="cuda"); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
 kw = {"write": dict(want_out=True), "pre": dict(want_out=False, want_argmax=True, argmax_value_only=True),
-      "main": dict(want_out=True, phase_table=ph), "all": dict(want_out=True, phase_table=ph, want_argmax=True)}[var]
+      "main": dict(want_out=True, phase_table=ph), "all": dict(want_out=True, phase_table=ph, want_argmax=True, argmax_value_only=True)}[var]
 for _ in range(int(os.environ.get("REPS", 3))):
     dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=am, argidx=ai, **kw)
 torch.cuda.synchronize()

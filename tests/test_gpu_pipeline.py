@@ -166,3 +166,41 @@ def test_run_stream_equals_one_dataset_at_a_time(mods, overlap):
         assert (r.p0, r.p1) == (ref_res.p0, ref_res.p1), k
         assert torch.equal(od, ref_out), k
         assert trace[k]["pre0"].elapsed_time(trace[k]["main1"]) > 0
+
+
+def test_run_stream_speculative_hits_and_repairs(mods, oracle):
+    """speculate=True guesses the winning row from the windowed L1 norms, verifies it against the true per-row
+    maxima the main pass returns, and repairs a wrong guess in place.  Datasets 0-2: rows of one spectral shape
+    (the guess is right); datasets 3-4: one row carries thirty unit resonances (largest L1 norm, peaks of height
+    about one) while the global maximum sits in a row with a single line of height 2.5 -- the guess is wrong and must
+    be repaired.  Either way
+    every output equals the non-speculative result (same winner, same (p0, p1), spectra to one rounding)."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 80, 1024, 2048
+    t = np.arange(nt) * 2e-4
+    sets = []
+    for k in range(5):
+        x, _ = _three_peak(nv, nt, 2e-4, seed=300 + k)
+        x[nv // 3] *= 0.3
+        x[(11 * k + 5) % nv] *= 2.5
+        if k >= 3:  # thirty unit lines in one row: its L1 norm adds up (~5 single lines), its peaks do not
+            x *= 0.05
+            lines = np.random.default_rng(k).uniform(-2300.0, 2300.0, 30)
+            x[7] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * f0 * t) for f0 in lines)
+            x[50] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -400.0 * t)
+        sets.append(dev.to_device(x.astype(np.complex64)))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=torch.complex64, device="cuda") for _ in sets]
+    ref_outs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, ref_outs, plan)
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["hit", "hit", "hit", "repaired", "repaired"]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert (a.flat_index, a.target_idx, a.pivot) == (b.flat_index, b.target_idx, b.pivot), k
+        assert (a.p0, a.p1) == (b.p0, b.p1), k
+        scale = float(ref_outs[k].abs().max())
+        assert float((outs[k] - ref_outs[k]).abs().max()) < (1e-6 if a.speculation == "repaired" else 1e-12) * scale + 0.0, k
+    assert got[3].flat_index // target == 50

@@ -261,6 +261,25 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
   return XM_OK;
 }
 
+int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int pad_left,
+              void* norm, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n_in, dtype);
+  if (rc) return rc;
+  if (!norm || pad_left < 0 || in_row_stride < n_in) return fail(XM_ERR_INVALID_ARG, "row_l1: bad arguments");
+  if (n_batch == 0) return XM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)(n_batch < 256 * 16 ? n_batch : 256 * 16);
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_row_l1<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in, (long long)in_row_stride,
+                       (const float*)window, (long long)n_batch, n_in, pad_left, (float*)norm);
+  else
+    hipLaunchKernelGGL(k_row_l1<double>, dim3(grid), dim3(256), 0, st, (const Cx<double>*)in,
+                       (long long)in_row_stride, (const double*)window, (long long)n_batch, n_in, pad_left,
+                       (double*)norm);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
 int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch, int n, void* out_max2,
                      int64_t* out_flat, int dtype, void* stream) {
   if (!absmax2 || !argidx || !out_max2 || !out_flat || n_batch < 1 || n < 1)

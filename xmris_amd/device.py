@@ -350,6 +350,21 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
                        argidx if want_argmax else None)
 
 
+def row_l1(x2, window=None, pad_left: int = 0, out=None):
+    """Windowed L1 norm of every row of ``x2`` = [n_batch, n_in] (`xm_row_l1`): the cheap streaming guess for
+    the row that holds the global maximum of the spectra."""
+    _require_device(x2)
+    torch = _torch()
+    if x2.dim() != 2 or not x2.is_contiguous():
+        raise ValueError("row_l1 expects a contiguous [n_batch, n_in] tensor")
+    nb, n_in = x2.shape
+    if out is None:
+        out = torch.empty(nb, dtype=_real_dtype(x2), device=x2.device)
+    _lib.call("xm_row_l1", x2.data_ptr(), n_in, window.data_ptr() if window is not None else None, nb, n_in,
+              int(pad_left), out.data_ptr(), _dtype_code(x2), _stream(x2))
+    return out
+
+
 def argmax_reduce(absmax2, argidx, n: int):
     """Global (max |X|, flat index) from the per-spectrum pairs of a fused launch."""
     torch = _torch()

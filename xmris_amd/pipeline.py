@@ -83,6 +83,7 @@ class AutophaseResult:
     timing: dict = field(default_factory=dict)
     owner: int = 0      # rank that owns the winning spectrum (run_stream)
     mine: bool = True   # ... and whether that is this rank
+    speculation: str = ""  # run_stream(speculate=True): "hit" or "repaired"
 
 
 class Selection:
@@ -210,7 +211,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
 
 def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=None, rank_offset_rows: int = 0,
                overlap: bool = True, method: str = "acme", peak_width=100, target_coord=None, p0_only: bool = False,
-               trace: list | None = None):
+               trace: list | None = None, speculate: bool = False):
     """The fused hot path over a SEQUENCE of independent datasets of one shape, software-pipelined.
 
     ``inputs[i]`` ([n_batch, n_in] complex rows in HBM) is transformed into ``outputs[i]`` ([n_batch, n_out]);
@@ -225,9 +226,20 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
     the per-rank winners and `broadcast(values, owner) -> values` hands the owner's (p0, p1) to every rank
     (`xmris_amd.sharding`); `rank_offset_rows` = first global row of this rank's shard.
 
+    `speculate=True` replaces the arg-max pre-pass (an FFT of every row, instruction bound) by a GUESS of the
+    winning row from the windowed L1 norm of the FIDs (`xm_row_l1`, a streaming read at HBM speed:
+    sum|z|/sqrt(N) bounds every |X[k]| of a row and equals the peak of a single decaying resonance).  (p0, p1)
+    is searched on the guessed row's spectrum, the main pass applies it AND returns the true per-row maxima, and
+    the true global arg-max row is compared with the guess before the next main pass is queued.  A wrong guess
+    is repaired exactly: the true row's spectrum is fetched, (p0, p1) searched again and the dataset's output
+    multiplied in place by e^{i (phi_true - phi_guess)}; results equal the non-speculative schedule's up to one
+    rounding of the storage precision.  How often the guess is right depends on the data (rows of similar
+    spectral shape: always); correctness never does.
+
     `trace`, if given, receives one dict per dataset: host timestamps (`t_start`, `t_exchanged`, `t_solved`,
     `t_table`) and torch events around the two kernels (`pre0`, `pre1`, `main0`, `main1`).
-    Returns the list of AutophaseResult (p0, p1 filled on every rank)."""
+    Returns the list of AutophaseResult (p0, p1 filled on every rank; `.speculation` = "hit" / "repaired" with
+    `speculate`)."""
     import time
 
     import torch
@@ -237,6 +249,11 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
         raise ValueError("inputs and outputs must have the same length")
     if n_sets == 0:
         return []
+    if speculate:
+        if target_coord is not None:
+            raise ValueError("speculate=True needs the arg-max pivot (target_coord=None)")
+        return _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
+                                       peak_width, p0_only, trace)
     n = plan.n_out
     x0 = inputs[0]
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
@@ -303,6 +320,136 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
         results.append(res)
         if trace is not None:
             trace.append(ev)
+    return results
+
+
+def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
+                            peak_width, p0_only, trace):
+    """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair)."""
+    import time
+
+    import torch
+
+    n_sets, n = len(inputs), plan.n_out
+    x0 = inputs[0]
+    nb = x0.shape[0]
+    rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
+    key = ("spec_bufs", nb, str(rd))
+    bufs = plan.extra.get(key)
+    if bufs is None:
+        bufs = plan.extra[key] = dict(
+            norm=[torch.empty(nb, dtype=rd, device=x0.device) for _ in range(2)],
+            zero_idx=torch.zeros(nb, dtype=torch.int32, device=x0.device),
+            tmax=[torch.empty(nb, dtype=rd, device=x0.device) for _ in range(2)],
+            tidx=[torch.empty(nb, dtype=torch.int32, device=x0.device) for _ in range(2)],
+            vmax=[torch.empty(1, dtype=rd, pin_memory=True) for _ in range(2)],
+            vflat=[torch.empty(1, dtype=torch.int64, pin_memory=True) for _ in range(2)])
+    sel = [None, None]
+    events = [dict() for _ in range(n_sets)]
+    results = []
+    iw = aps.index_width_of(plan.freq, peak_width)
+
+    def guess(i):  # streaming L1 norms + the selection stage on the row with the largest one
+        b = i & 1
+        ev = events[i]
+        if trace is not None:
+            ev["pre0"], ev["pre1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev["pre0"].record()
+        dev.row_l1(inputs[i], plan.window, plan.pad_left, out=bufs["norm"][b])
+        if trace is not None:
+            ev["pre1"].record()
+        sel[b] = Selection(inputs[i], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True)
+
+    def search(sl, k, pivot):
+        p0, p1, opt = aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only)
+        return p0, p1, opt
+
+    def verify(i):
+        """True global arg-max row of dataset i (its main pass has been queued) against the guess; repair."""
+        b = i & 1
+        res, ev = results[i], events[i]
+        ev["verify_event"].synchronize()
+        tmax, trow = float(bufs["vmax"][b].item()) ** 0.5, int(bufs["vflat"][b].item()) // n
+        g_row, owner = rank_offset_rows + trow, 0
+        mine = True
+        if exchange is not None:
+            mine, gflat, owner = exchange(tmax, (rank_offset_rows + trow) * n)
+            g_row = gflat // n
+        if g_row == res.flat_index // n:
+            res.speculation = "hit"
+            if mine:
+                res.max_abs = tmax  # the guess stage only knew the L1 norm
+            return
+        # wrong guess: the owner of the true row fetches its spectrum (fp64), searches again, everyone rotates
+        vals = [0.0, 0.0, 0.0, 0.0]
+        if mine:
+            row = g_row - rank_offset_rows
+            x1 = inputs[i][row:row + 1].to(torch.complex128)
+            sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out[0].cpu().numpy()
+            k = int(np.argmax(np.abs(sl)))
+            p0, p1, opt = search(sl, k, float(plan.freq[k]))
+            vals = [p0, p1, float(k), float(opt.nfev)]
+        if broadcast is not None:
+            vals = broadcast(vals, owner)
+        p0, p1, k = float(vals[0]), float(vals[1]), int(vals[2])
+        pivot = float(plan.freq[k])
+        ratio = np.exp(1j * (aps.phase_angles(plan.freq, p0, p1, pivot)
+                             - aps.phase_angles(plan.freq, res.p0, res.p1, res.pivot)))
+        if np.ndim(ratio) == 0:
+            ratio = np.full(n, ratio)
+        rt = torch.from_numpy(np.ascontiguousarray(ratio)).to(outputs[i].device, outputs[i].dtype)
+        from . import _lib
+
+        o = outputs[i]
+        _lib.call("xm_phase_apply", o.data_ptr(), o.data_ptr(), rt.data_ptr(), o.shape[0], n, dev._dtype_code(o),
+                  dev._stream(o))
+        res.p0, res.p1, res.pivot, res.target_idx = p0, p1, pivot, k
+        res.flat_index, res.max_abs, res.owner, res.mine = g_row * n + k, tmax, owner, mine
+        res.nfev = int(vals[3]) if mine else 0
+        res.speculation = "repaired"
+
+    guess(0)
+    for i in range(n_sets):
+        b = i & 1
+        ev = events[i]
+        ev["t_start"] = time.perf_counter()
+        amax, flat, sl = sel[b].wait()  # (largest L1 norm, guessed row * n + arg-max of its fp64 spectrum, spectrum)
+        gflat, mine, owner = rank_offset_rows * n + flat, True, 0
+        if exchange is not None:  # the guess is global too: the rank with the largest norm owns it
+            mine, gflat, owner = exchange(amax, gflat)
+        ev["t_exchanged"] = time.perf_counter()
+        if overlap and i + 1 < n_sets:
+            guess(i + 1)
+        k = gflat % n
+        res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), amax)
+        if mine:
+            p0, p1, opt = search(sl, int(k), res.pivot)
+            res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
+            res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
+        if broadcast is not None:
+            res.p0, res.p1 = broadcast([res.p0, res.p1], owner)
+        res.owner, res.mine = owner, mine
+        ev["t_solved"] = time.perf_counter()
+        ph = upload_phase_table(plan, inputs[i], res.p0, res.p1, res.pivot)
+        ev["t_table"] = time.perf_counter()
+        results.append(res)
+        if i > 0:  # dataset i-1's main pass is done (or about to be): settle its guess before outputs are reused
+            verify(i - 1)
+        if trace is not None:
+            ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev["main0"].record()
+        dev.pipeline_fused(inputs[i], n, plan.pad_left, window=plan.window, phase_table=ph, out=outputs[i],
+                           want_argmax=True, absmax2=bufs["tmax"][b], argidx=bufs["tidx"][b], argmax_value_only=True)
+        if trace is not None:
+            ev["main1"].record()
+        dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
+        ev["verify_event"] = torch.cuda.Event()
+        ev["verify_event"].record()
+        if not overlap and i + 1 < n_sets:
+            guess(i + 1)
+        if trace is not None:
+            trace.append(ev)
+    verify(n_sets - 1)
     return results
 
 
