@@ -3,7 +3,9 @@
 # Regenerates everything under profiles/<round-tag>/ source data (written to gpurun_out/<round-tag>/):
 #   1. bench.py unprofiled            -> bench_unprofiled.json
 #   2. bench.py under rocprofv3 stats -> bench_under_rocprof.json, bench_kernel_stats.csv, bench_kernel_trace_xm_kernels.csv
-#   3. separate --pmc passes for the main kernel and the pre-pass -> pmc_main_kernel.txt, pmc_prepass_kernel.txt
+#   3. separate --pmc passes for the main kernel (speculative schedule: write + phase + per-row maxima), the guess
+#      kernel (xm_row_l1) and the classic schedule's pre-pass -> pmc_main_kernel.txt, pmc_guess_kernel.txt,
+#      pmc_prepass_kernel.txt
 set -e -o pipefail
 tag=${1:-r01}
 out=gpurun_out/$tag
@@ -22,8 +24,11 @@ PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CY
         "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
         "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum")
 rm -rf gpurun_out/pmc_${tag}main_* gpurun_out/pmc_${tag}pre_*
-bash scripts/pmc.sh ${tag}main main "${PMC_GROUPS[@]}" > $out/pmc_main_kernel.txt
+bash scripts/pmc.sh ${tag}main all "${PMC_GROUPS[@]}" > $out/pmc_main_kernel.txt
 echo "main-kernel counters done"
+rm -rf gpurun_out/pmc_${tag}guess_*
+bash scripts/pmc.sh ${tag}guess guess "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU" > $out/pmc_guess_kernel.txt
+rm -rf gpurun_out/pmc_${tag}guess_*
 bash scripts/pmc.sh ${tag}pre pre "${PMC_GROUPS[@]}" > $out/pmc_prepass_kernel.txt
 rm -rf gpurun_out/pmc_${tag}main_* gpurun_out/pmc_${tag}pre_*
 echo "collected into $out"
