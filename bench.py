@@ -202,6 +202,13 @@ def main():
 
     if args.warmup:
         run_steps(args.warmup, False)
+    # A full (generation-2) garbage collection over the interpreter's ~10^5 long-lived objects (torch, numpy) takes
+    # 10+ ms -- five steps.  Collect now and move everything alive into the permanent generation: the cyclic
+    # garbage the timed loop creates is then collected in microseconds.
+    import gc
+
+    gc.collect()
+    gc.freeze()
     barrier()
     t_start = time.perf_counter()
     run_steps(args.steps, True)

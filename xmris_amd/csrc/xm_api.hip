@@ -268,7 +268,8 @@ int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t
   if (!norm || pad_left < 0 || in_row_stride < n_in) return fail(XM_ERR_INVALID_ARG, "row_l1: bad arguments");
   if (n_batch == 0) return XM_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = (int)(n_batch < 256 * 16 ? n_batch : 256 * 16);
+  const int64_t want = (n_batch + 3) / 4;  // four rows (waves) per workgroup
+  const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_row_l1<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in, (long long)in_row_stride,
                        (const float*)window, (long long)n_batch, n_in, pad_left, (float*)norm);

@@ -1076,25 +1076,28 @@ __global__ __launch_bounds__(256) void k_absmax_rows(const Cx<T>* __restrict__ i
 // sum_j |z_j| / sqrt(N) bounds every |X[k]| of the row from above and equals the peak height of a single
 // decaying resonance, so the row with the largest norm is the natural GUESS for the row that holds the global
 // arg-max (autophase's speculative schedule; the guess is verified against the true maxima afterwards).
-// Streaming read, 256 threads per row, persistent grid.
+// Streaming read, one wave per row, persistent grid.
 template <class T>
 __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, long long in_stride,
                                                  const T* __restrict__ window, long long n_batch, int n_in,
                                                  int pad_left, T* __restrict__ norm) {
-  __shared__ T red[4];
-  constexpr int UN = 8;  // independent 16-byte loads in flight per thread and round (read-only streaming)
+  // one WAVE per row (four rows per workgroup): no LDS, no barriers, a shuffle reduction at the end of the row
+  constexpr int UN = 8;  // independent 16-byte loads in flight per lane and round (read-only streaming)
   constexpr int PER = 16 / (int)sizeof(Cx<T>);  // samples per 16-byte load: 2 (complex64) or 1 (complex128)
   const bool wide = PER == 1 || ((in_stride & 1) == 0 && (n_in & 1) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0);
-  for (long long b = blockIdx.x; b < n_batch; b += gridDim.x) {
+  const int lane = threadIdx.x & (XM_WAVE - 1);
+  const long long wave = (long long)blockIdx.x * (256 / XM_WAVE) + (threadIdx.x / XM_WAVE);
+  const long long nwaves = (long long)gridDim.x * (256 / XM_WAVE);
+  for (long long b = wave; b < n_batch; b += nwaves) {
     const Cx<T>* __restrict__ row = in + b * in_stride;
     T acc = T(0);
     if (wide) {
       const int nvec = n_in / PER;
-      for (int j0 = threadIdx.x; j0 < nvec; j0 += 256 * UN) {
+      for (int j0 = lane; j0 < nvec; j0 += XM_WAVE * UN) {
         Cx<T> x[UN][PER];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int j = j0 + 256 * u;
+          const int j = j0 + XM_WAVE * u;
           if (j < nvec) {
             const xm_u4 raw = *reinterpret_cast<const xm_u4*>(row + (long long)j * PER);
             __builtin_memcpy(&x[u][0], &raw, 16);
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int j = (j0 + 256 * u) * PER;
+          const int j = (j0 + XM_WAVE * u) * PER;
 #pragma unroll
           for (int e = 0; e < PER; ++e) {
             const T m = sqrt(x[u][e].re * x[u][e].re + x[u][e].im * x[u][e].im);
@@ -1114,18 +1117,15 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
         }
       }
     } else {
-      for (int j = threadIdx.x; j < n_in; j += 256) {
+      for (int j = lane; j < n_in; j += XM_WAVE) {
         const Cx<T> x = row[j];
         const T m = sqrt(x.re * x.re + x.im * x.im);
         acc += window ? m * fabs(window[j + pad_left]) : m;
       }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_t(acc, m);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) norm[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int m = XM_WAVE / 2; m >= 1; m >>= 1) acc += shfl_xor_t(acc, m);
+    if (lane == 0) norm[b] = acc;
   }
 }
 
