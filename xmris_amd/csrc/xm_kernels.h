@@ -475,7 +475,19 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
           bi = min(bi, mo == bv ? k0 + 1 : 0x7fffffff);
         }
       }
-      amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+      if constexpr (PACKED && NT > XM_WAVE) {
+        if (A.amax_value_only) {
+          // value only: one atomic max per wave into the row's slot (zeroed by the launcher; squared magnitudes
+          // order like their bit patterns) -- no LDS slot, no workgroup barrier
+          const unsigned key = wave_reduce_u32<true>(__float_as_uint(bv));
+          if ((tt & (XM_WAVE - 1)) == 0u) atomicMax(reinterpret_cast<unsigned*>(A.absmax2 + s), key);
+          if (tt == 0u) A.argidx[s] = 0;
+        } else {
+          amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+        }
+      } else {
+        amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+      }
     }
     if constexpr (WRITE) {
       Cx<T>* __restrict__ orow = A.out + s * (long long)N;
