@@ -350,9 +350,10 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
                        argidx if want_argmax else None)
 
 
-def row_l1(x2, window=None, pad_left: int = 0, out=None):
+def row_l1(x2, window=None, pad_left: int = 0, out=None, n_used: int | None = None):
     """Windowed L1 norm of every row of ``x2`` = [n_batch, n_in] (`xm_row_l1`): the cheap streaming guess for
-    the row that holds the global maximum of the spectra."""
+    the row that holds the global maximum of the spectra.  `n_used` < n_in sums only the leading samples of
+    every row (a caller that knows the window's tail carries no weight skips reading it)."""
     _require_device(x2)
     torch = _torch()
     if x2.dim() != 2 or not x2.is_contiguous():
@@ -360,7 +361,8 @@ def row_l1(x2, window=None, pad_left: int = 0, out=None):
     nb, n_in = x2.shape
     if out is None:
         out = torch.empty(nb, dtype=_real_dtype(x2), device=x2.device)
-    _lib.call("xm_row_l1", x2.data_ptr(), n_in, window.data_ptr() if window is not None else None, nb, n_in,
+    n_sum = n_in if n_used is None else max(1, min(int(n_used), n_in))
+    _lib.call("xm_row_l1", x2.data_ptr(), n_in, window.data_ptr() if window is not None else None, nb, n_sum,
               int(pad_left), out.data_ptr(), _dtype_code(x2), _stream(x2))
     return out
 

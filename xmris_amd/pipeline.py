@@ -370,6 +370,17 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     events = [dict() for _ in range(n_sets)]
     results = []
     iw = aps.index_width_of(plan.freq, peak_width)
+    # The guess needs a ranking, not the norm itself: samples whose window weight is negligible are not read.
+    # n_used = the leading samples that carry all but 1e-3 of the window's total weight (rounded up to 256).
+    n_used = plan.extra.get("guess_n_used")
+    if n_used is None:
+        wabs = np.abs(np.asarray(plan.window_host, dtype=np.float64)[plan.pad_left:plan.pad_left + plan.n_in])
+        total = float(wabs.sum())
+        n_used = plan.n_in
+        if total > 0:
+            n_used = int(np.searchsorted(np.cumsum(wabs), (1.0 - 1e-3) * total)) + 1
+            n_used = min(plan.n_in, max(256, -(-n_used // 256) * 256))
+        plan.extra["guess_n_used"] = n_used
 
     def guess(i):  # streaming L1 norms + the selection stage on the row with the largest one
         b = i & 1
@@ -377,7 +388,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         if trace is not None:
             ev["pre0"], ev["pre1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["pre0"].record()
-        dev.row_l1(inputs[i], plan.window, plan.pad_left, out=bufs["norm"][b])
+        dev.row_l1(inputs[i], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used)
         if trace is not None:
             ev["pre1"].record()
         sel[b] = Selection(inputs[i], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True)
