@@ -267,7 +267,9 @@ XM_DEV void static_for(F&& f) {
 //     + 2t with shift a multiple of 2*NT -- a scalar base per q plus one per-lane offset, so all
 //     addressing is SGPR base + 32-bit lane offset, and each lane stores one 16-byte (c64) word.
 // MODE bits: 1 = write the spectrum, 2 = multiply by the phase table, 4 = per-spectrum arg-max.
-enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4 };
+// ZF2_VALUE_ONLY: the arg-max part is compiled WITHOUT the first-index scan (complex128 write + arg-max modes: the
+// scan's live state pushed them over 256 VGPRs); the runtime flag PipeArgs::amax_value_only alone only skips it.
+enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4, ZF2_VALUE_ONLY = 16 };
 
 // waves per SIMD the register allocator must leave room for: two resident workgroups per CU
 template <class T, class PL>
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
   // packed multiplies + two FMAs instead of ~11 scalar operations (window, rotation, W_2P^q, lane packing).
   constexpr bool FOLD = PACKED && MODE == ZF2_AMAX;
   constexpr bool SEQ = !PACKED && MODE == ZF2_AMAX;
+  constexpr bool CVO = (MODE & ZF2_VALUE_ONLY) != 0;
   Cx<T> wr[FOLD ? P : 1];
   if constexpr (FOLD) {
     static_for<0, P>([&](auto qc) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         bv = fmax(bv, fmax(me, mo));
       }
       int bi = 0;
-      if (!A.amax_value_only) {  // wave-uniform
+      if (!CVO && !A.amax_value_only) {  // wave-uniform (CVO: compiled out)
         bi = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
