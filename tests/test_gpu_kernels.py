@@ -386,3 +386,24 @@ def test_clear_cache_between_launches(dev, oracle):
     assert np.array_equal(dev.fft(xd, 1, shift_out=True).cpu().numpy(), a1)
     assert np.array_equal(dev.pipeline_fused(zd, 4096, 0).out.cpu().numpy(), b1)
     assert _relerr(a1, oracle.to_spectrum_values(x.astype(np.complex128), 1)) < 4 * TIGHT["complex64"]
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("nb,n_in,pad_left,n_used", [(9, 4096, 0, None), (9, 4096, 0, 2304), (7, 1531, 3, None),
+                                                      (5, 1000, 0, 257), (1, 64, 10, None), (300, 512, 0, None)])
+def test_row_l1_matches_numpy(dev, nb, n_in, pad_left, n_used, dtype):
+    """xm_row_l1: windowed L1 norm of every row (the speculative schedule's guess), wide and scalar load paths,
+    a window offset by the left pad, no window, and the truncated sum."""
+    import torch
+
+    x = _rand((nb, n_in), dtype, seed=n_in + nb)
+    w = np.linspace(1.5, 0.1, n_in + 2 * pad_left + 5) * np.where(np.arange(n_in + 2 * pad_left + 5) % 7 == 0, -1.0, 1.0)
+    xd = dev.to_device(x)
+    rd = torch.float32 if dtype == "complex64" else torch.float64
+    wd = torch.from_numpy(w).to("cuda", rd)
+    m = n_in if n_used is None else n_used
+    ref_w = (np.abs(x.astype(np.complex128))[:, :m] * np.abs(w[pad_left:pad_left + m])).sum(axis=1)
+    ref_1 = np.abs(x.astype(np.complex128))[:, :m].sum(axis=1)
+    tol = 2e-6 if dtype == "complex64" else 1e-13
+    np.testing.assert_allclose(dev.row_l1(xd, wd, pad_left, n_used=n_used).cpu().numpy(), ref_w, rtol=tol)
+    np.testing.assert_allclose(dev.row_l1(xd, None, 0, n_used=n_used).cpu().numpy(), ref_1, rtol=tol)
