@@ -266,6 +266,8 @@ def main():
             "phase_table_and_upload": float(np.mean(times["table_ms"])),
             "device_period_min_median_max": ([float(np.min(times["period_ms"])), float(np.median(times["period_ms"])),
                                               float(np.max(times["period_ms"]))] if times["period_ms"] else None),
+            "device_period_p90_p99": ([float(np.percentile(times["period_ms"], 90)),
+                                       float(np.percentile(times["period_ms"], 99))] if times["period_ms"] else None),
             "streaming_spectra_per_s_per_gpu": nv / (stream_ms * 1e-3),
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },

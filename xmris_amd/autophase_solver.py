@@ -81,11 +81,13 @@ def index_width_of(coords: np.ndarray, peak_width: float) -> int:
 
 
 def default_threads() -> int:
-    """Team size for the native objective: at most 16, at most this process's share of the CPUs it may use
-    (scheduler affinity and the cgroup v2 quota, divided by the ranks torchrun started on this node) -- spinning
-    workers beyond the quota are throttled by the kernel and slow the search down instead of speeding it up."""
+    """Team size for the native objective: a power of two, at most 16 and at most HALF of this process's share of
+    the CPUs it may use (scheduler affinity and the cgroup v2 quota, divided by the ranks torchrun started on
+    this node)."""
     import os
 
+    if os.environ.get("XM_SOLVER_THREADS"):  # tuning switch
+        return max(1, min(32, int(os.environ["XM_SOLVER_THREADS"])))
     try:
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -98,7 +100,16 @@ def default_threads() -> int:
     except (OSError, ValueError):
         pass
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    return max(1, min(16, cpus // local_world))
+    # Half of the share, as a power of two (the work units of a batch are 4 evaluations x 4 parts): a team that
+    # fills the whole CPU quota while it spins leaves no headroom for the HIP runtime's threads, and a cgroup that
+    # overdraws its quota is frozen until the next 100 ms period -- measured as rare 15-25 ms stalls of the whole
+    # pipeline with 16 threads on a 16-CPU share, none with 8 (the search takes 0.95 instead of 0.71 ms, still
+    # hidden behind the device).
+    share = max(1, cpus // local_world // 2)
+    team = 1
+    while team * 2 <= min(16, share):
+        team *= 2
+    return team
 
 
 class NativeObjective:
