@@ -152,6 +152,12 @@ int xm_solver_set_threads(void* solver, int threads);
 int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxiter, double* x_out /*[2]*/,
                  double* fun_out, int* nfev_out, int* nit_out);
 
+/* A8, host side: the phase table e^{i phi}, phi[k] = rad(p0) + rad(p1) * (coords[k] - pivot) / (max - min coords)
+ * (processing/phasing.py:56-73; scalar phase for a zero range), fp64 arithmetic rounded once to the storage
+ * precision.  `out`: n interleaved (re, im) pairs in HOST memory, float32 if as_float != 0 else float64 (the caller's
+ * pinned staging buffer for xm_phase_apply / xm_pipeline_fused).  Returns 0, or -1 for bad arguments. */
+int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, double pivot, void* out, int as_float);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,7 @@ SIGNATURES = {
     "xm_gather_row_c128": (_i, [_p, _l, _i, _p, _i, _p, _i, _p]),
     "xm_pipeline_fused": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
     "xm_row_l1": (_i, [_p, _l, _p, _l, _i, _i, _p, _i, _p]),
+    "xm_phase_table": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p, _i]),
     "xm_solver_create": (_p, [_p, _p, _i, ctypes.c_double, _i, _i, _i]),
     "xm_solver_destroy": (None, [_p]),
     "xm_solver_score": (ctypes.c_double, [_p, _p, _i]),

@@ -425,6 +425,45 @@ void xm_solver_score_batch(void* h, const double* xs, int nx, int count, double*
 
 int xm_solver_get_batch(void* h) { return ((Solver*)h)->batch; }
 
+// e^{i phi} over a coordinate axis, phi = rad(p0) + rad(p1) * (c - pivot) / (max c - min c)  (scalar phase when the
+// range is zero; reference processing/phasing.py:56-73), computed in fp64 and rounded once to the storage
+// precision: `out` = n interleaved (re, im) pairs of float32 (as_float != 0) or float64.  Host memory (the caller's
+// pinned staging buffer).  The cos and sin loops are separate so that the vector math library is used.
+int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, double pivot, void* out, int as_float) {
+  if (!coords || !out || n < 1) return -1;
+  double cmin = coords[0], cmax = coords[0];
+  for (int k = 1; k < n; ++k) {
+    cmin = std::min(cmin, coords[k]);
+    cmax = std::max(cmax, coords[k]);
+  }
+  const double kRad = M_PI / 180.0, range = cmax - cmin;
+  const double p0r = p0_deg * kRad, p1r = p1_deg * kRad;
+  std::vector<double> ang(n), cs(n), sn(n);
+  if (range == 0) {
+    std::fill(ang.begin(), ang.end(), p0r);
+  } else {
+    for (int k = 0; k < n; ++k) ang[k] = p0r + p1r * ((coords[k] - pivot) / range);
+  }
+#pragma omp simd
+  for (int k = 0; k < n; ++k) cs[k] = std::cos(ang[k]);
+#pragma omp simd
+  for (int k = 0; k < n; ++k) sn[k] = std::sin(ang[k]);
+  if (as_float) {
+    float* o = (float*)out;
+    for (int k = 0; k < n; ++k) {
+      o[2 * k] = (float)cs[k];
+      o[2 * k + 1] = (float)sn[k];
+    }
+  } else {
+    double* o = (double*)out;
+    for (int k = 0; k < n; ++k) {
+      o[2 * k] = cs[k];
+      o[2 * k + 1] = sn[k];
+    }
+  }
+  return 0;
+}
+
 // One search at a time owns the pool (two Python threads may call xm_solver_de concurrently).
 static std::mutex g_search_mu;
 

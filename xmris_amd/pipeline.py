@@ -498,14 +498,16 @@ def upload_phase_table(plan: PipelinePlan, like, p0: float, p1: float, pivot: fl
         stage = plan.extra[key] = [torch.empty(n, dtype=like.dtype, pin_memory=True) for _ in range(2)] + [0]
     stage[2] ^= 1
     host = stage[stage[2]]
-    ang = aps.phase_angles(plan.freq, p0, p1, pivot)
-    view = host.numpy()
-    if np.ndim(ang) == 0:
-        view[:] = np.exp(1.0j * ang)
-    else:  # cos/sin straight into the staging buffer's (re, im) lanes: same values as np.exp(1j*ang)
-        pair = view.view(np.float32 if like.dtype == torch.complex64 else np.float64).reshape(n, 2)
-        pair[:, 0] = np.cos(ang)
-        pair[:, 1] = np.sin(ang)
+    # fp64 cos / sin of the ramp, rounded once, written straight into the pinned staging buffer by the host library
+    from . import _lib
+
+    freq = plan.extra.get("freq_c")
+    if freq is None:
+        freq = plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
+    rc = _lib.load().xm_phase_table(freq.ctypes.data, n, float(p0), float(p1), float(pivot), host.data_ptr(),
+                                    1 if like.dtype == torch.complex64 else 0)
+    if rc:
+        raise ValueError("xm_phase_table rejected its arguments")
     dev_t = plan.extra.setdefault(("phase_dev", str(like.dtype)),
                                   [torch.empty(n, dtype=like.dtype, device=like.device) for _ in range(2)])
     out = dev_t[stage[2]]
