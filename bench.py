@@ -88,6 +88,13 @@ def main():
                     help="N > 1: the O(1) host exchange goes through a shared-memory page (one node) or gloo")
     args = ap.parse_args()
 
+    # Libraries chat on stdout (RCCL prints a five-line banner at communicator creation, gloo a line per rank): the
+    # contract is ONE JSON line there.  File descriptor 1 is pointed at stderr for the whole run; the result line goes
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     from xmris_amd import autophase_solver as aps
@@ -286,7 +293,8 @@ def main():
         result["cpu_baseline_all_cores"] = cpu_baseline_threads(x, t, N, args.lb, nv,
                                                                 result["cpu_baseline"]["de_solve_s"])
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
