@@ -2,20 +2,24 @@
 """bench.py -- spectra/s of the xmris `.xmr` hot path on MI355X.
 
 One "step" = one full pass of  zero_fill -> apodize_exp -> to_spectrum -> autophase  over one
-synthetic batch that is already resident in HBM:
-    pre-pass kernel (fused zero-fill + window + FFT + |X|^2 arg-max, nothing written)
- -> global arg-max (device reduce, 16 B to the host; over ranks: one tiny all_gather)
- -> the arg-max spectrum (one workgroup, 64 KiB D2H) -> host differential evolution (p0, p1)
- -> phase table (fp64 on the host, 64 KiB H2D)
- -> main kernel (fused zero-fill + window + FFT + fftshift + phase, reads the FID, writes the spectrum)
-Nothing is skipped or cached between steps.  Steps are independent datasets, so by default the
-pre-pass kernel of step i+1 is queued while the host solves step i (`--no-overlap` serialises them).  Workload at N=1: BASELINE.json configs[2]
-(65,536 voxels x 4096-pt complex64 FIDs zero-filled to 8192).  With --gpus N every rank owns its
-own 65,536-voxel shard of ONE dataset (weak scaling); the only cross-rank traffic is the O(1)
-arg-max exchange and the (p0, p1) broadcast.
+synthetic batch that is already resident in HBM, run by the library's streaming executor
+`xmris_amd.pipeline.run_stream`.  Default (speculative) schedule, per step:
+    guess kernel (xm_row_l1: windowed L1 norm of every FID, streaming read) -> row with the largest norm
+ -> that row's spectrum recomputed in complex128 (one workgroup, written to pinned host memory)
+ -> host differential evolution (p0, p1) -> phase table (fp64 on the host, 64 KiB H2D)
+ -> main kernel (fused zero-fill + window + FFT + fftshift + phase + per-row max |X|^2; reads the FIDs, writes
+    the spectra) -> device reduction of the TRUE global arg-max -> compared with the guess before the next main
+    pass is queued; a wrong guess is repaired exactly (never needed on this data; `speculation` in the JSON line)
+`--no-speculate`: the classic schedule -- an arg-max pre-pass (fused zero-fill + window + FFT + |X|^2 maxima,
+nothing written) finds the winning row before the search, the main kernel only writes.
+Over ranks: one O(1) exchange of (max, global flat index) per decision and one broadcast of (p0, p1).
+Nothing is skipped or cached between steps.  Steps are independent datasets, so by default the guess (or
+pre-pass) kernel of step i+1 is queued while the host solves step i (`--no-overlap` serialises them).
+Workload at N=1: BASELINE.json configs[2] (65,536 voxels x 4096-pt complex64 FIDs zero-filled to 8192).  With
+--gpus N every rank owns its own 65,536-voxel shard of ONE dataset (weak scaling).
 
-Prints ONE JSON line on rank 0 (see the driver contract); `roofline` prices the dominant (main)
-kernel by HIP events on its stream, `cpu_baseline` times the CPU oracle on a bounded sample.
+Prints ONE JSON line on rank 0's stdout (see the driver contract; library chatter goes to stderr); `roofline`
+prices the dominant (main) kernel by HIP events on its stream, `cpu_baseline` times the CPU oracle.
 """
 import argparse
 import json
