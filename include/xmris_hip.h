@@ -20,6 +20,8 @@
  *  - Twiddle / chirp tables are computed in fp64 on the host, rounded once to the storage
  *    precision and cached per (length, dtype, device) inside the library (mutex-guarded);
  *    `xm_clear_cache()` frees them.  Reentrant otherwise.
+ *  - Device: the device that owns the input buffer is made current for the duration of a call (tables, occupancy
+ *    caches and scratch are per device); `stream` must belong to that device.
  */
 #ifndef XMRIS_HIP_H
 #define XMRIS_HIP_H
@@ -47,6 +49,12 @@ typedef enum {
 #define XM_FFT_SHIFT_OUT 8u /* roll the OUTPUT by N/2 afterwards (fftshift, fourier.py:31)  */
 #define XM_AMAX_VALUE_ONLY 16u /* xm_pipeline_fused: absmax2[b] only, argidx[b] is written as 0 (the caller
                                   recovers the index along the axis from the winning spectrum itself)      */
+
+#define XM_AMAX_GLOBAL_KEY 32u /* xm_pipeline_fused(_ramp), geometries of xm_pipeline_ramp_native only: `absmax2` points to
+                                  an arg-max KEY BUFFER (XM_KEY_BYTES bytes, zero at launch) that receives the global
+                                  arg-max of the launch as partial keys, max |X|^2 float bits << 32 | (0xffffffff - row);
+                                  no per-row outputs, `argidx` unused.  xm_argmax_key_take merges, decodes and clears it. */
+#define XM_KEY_BYTES 8192     /* 64 partial keys on cache lines of their own */
 
 int xm_version(void); /* 10000*major + 100*minor + patch */
 const char* xm_last_error_string(void);
@@ -91,9 +99,22 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
  * resonance, so the row with the largest norm is the guess for the row through the global maximum
  * (phasing.py:229) that lets the host search (p0, p1) BEFORE any spectrum exists; the fused main pass then
  * returns the true per-row maxima, and a wrong guess is repaired (see xmris_amd/pipeline.py::run_stream).
+ * Only a ranking is needed, so the sum may run over a regular subset: the 1-KiB blocks (128 complex64 / 64
+ * complex128 samples) whose index is a multiple of `sub_step` (1 = every sample), i.e. whole cache lines spread
+ * over the n_in leading samples.
  * `norm`: n_batch reals of the storage precision. */
 int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int pad_left,
-              void* norm, int dtype, void* stream);
+              int sub_step, void* norm, uint64_t* key, int dtype, void* stream);
+/* `key` (complex64 only, may be NULL): an arg-max key buffer (XM_KEY_BYTES, zero at launch) that receives the row with
+ * the largest norm as float bits << 32 | (0xffffffff - row) -- the launch then needs no separate arg-max reduction;
+ * `norm` may be NULL. */
+
+/* A6: consumer of an arg-max key buffer written by xm_row_l1 / XM_AMAX_GLOBAL_KEY: out_max2[0] (float) = the value,
+ * out_flat[0] = row * n_per_row, buffer := 0 for its next producer.  With `in` (n_batch x n_in rows, dtype) also
+ * out_row[j] = (complex128) in[row, j] -- xm_gather_row_c128 of the winning row in the same launch.  `in` / `out_row`
+ * may be NULL.  out_* are device-accessible (the selection stage passes pinned host memory). */
+int xm_argmax_key_take(uint64_t* key, int n_per_row, void* out_max2, int64_t* out_flat, const void* in,
+                       int64_t in_row_stride, int n_in, void* out_row, int dtype, void* stream);
 
 /* A6  global arg-max  (phasing.py:229  np.argmax(np.abs(values)), first maximum in C order).
  * Reduces the per-spectrum pairs: out_max2[0] = max_b absmax2[b], out_flat[0] = b*n + argidx[b]
@@ -119,11 +140,24 @@ int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const vo
                       const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left,
                       unsigned flags, void* absmax2, int32_t* argidx, int dtype, void* stream);
 
+/* The fused hot path with the autophase ramp in closed form (A8, processing/phasing.py:62-73: on a uniform axis
+ * phi[k] = rad(p0) + rad(p1) * (c[k] - pivot) / range is linear in the output index k):
+ *   out[b, k] = X[k] * e^{i (phase0 + dphase * k)},   phase0 / dphase in radians, fp64.
+ * Everything else as xm_pipeline_fused (`out` must be given).  On the ">= 2x end zero fill" geometries of complex64
+ * (xm_pipeline_ramp_native) the kernel applies the ramp in factorised form -- no table exists, nothing is read per
+ * output; other geometries expand the ramp into a stream-ordered scratch table first. */
+int xm_pipeline_fused_ramp(const void* in, int64_t in_row_stride, void* out, const void* window, double phase0,
+                           double dphase, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                           void* absmax2, int32_t* argidx, int dtype, void* stream);
+/* 1 if xm_pipeline_fused_ramp applies the ramp natively for this geometry (see above), else 0. */
+int xm_pipeline_ramp_native(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags,
+                            int dtype);
+
 /* "next" (SURVEY 8f rank 4): asymmetric-least-squares baseline (processing/baseline.py:10-40 `_als_core`
  * applied along the last axis by `xr.apply_ufunc`, :102-110).  For every spectrum: n_iter rounds of
  * (W + lam*D'D) z = W y (pentadiagonal SPD, band LDL' in fp64) and w = p (y > z) + (1 - p) (y < z);
  * out[b, j] = y[b, j] - z[b, j] in float64, y = the REAL part of the input (is_complex) or the input itself
- * (real float32 / float64 for XM_C64 / XM_C128).  `workspace`: device scratch of
+ * (real float32 / float64 for XM_C64 / XM_C128); n >= 4.  `workspace`: device scratch of
  * xm_baseline_als_workspace_bytes(n_batch, n) bytes owned by the caller. */
 int64_t xm_baseline_als_workspace_bytes(int64_t n_batch, int n);
 int xm_baseline_als(const void* in, int is_complex, int64_t n_batch, int n, double lam, double p, int n_iter, void* out,

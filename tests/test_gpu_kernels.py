@@ -407,3 +407,8 @@ def test_row_l1_matches_numpy(dev, nb, n_in, pad_left, n_used, dtype):
     tol = 2e-6 if dtype == "complex64" else 1e-13
     np.testing.assert_allclose(dev.row_l1(xd, wd, pad_left, n_used=n_used).cpu().numpy(), ref_w, rtol=tol)
     np.testing.assert_allclose(dev.row_l1(xd, None, 0, n_used=n_used).cpu().numpy(), ref_1, rtol=tol)
+    # the sub-sampled ranking statistic: every 3rd 1-KiB block (128 complex64 / 64 complex128 samples) of the first m
+    per_block = 128 if dtype == "complex64" else 64
+    keep = ((np.arange(m) // per_block) % 3 == 0)
+    ref_s = (np.abs(x.astype(np.complex128))[:, :m] * np.abs(w[pad_left:pad_left + m]) * keep).sum(axis=1)
+    np.testing.assert_allclose(dev.row_l1(xd, wd, pad_left, n_used=n_used, sub_step=3).cpu().numpy(), ref_s, rtol=tol)

@@ -202,7 +202,9 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
         assert (a.flat_index, a.target_idx, a.pivot) == (b.flat_index, b.target_idx, b.pivot), k
         assert (a.p0, a.p1) == (b.p0, b.p1), k
         scale = float(ref_outs[k].abs().max())
-        assert float((outs[k] - ref_outs[k]).abs().max()) < (1e-6 if a.speculation == "repaired" else 1e-12) * scale + 0.0, k
+        # a hit applies the same (p0, p1) in a different instantiation of the kernel (with the per-row maxima): equal to
+        # one rounding of the storage precision; a repair multiplies by the phase ratio afterwards (two more roundings)
+        assert float((outs[k] - ref_outs[k]).abs().max()) < (1e-6 if a.speculation == "repaired" else 2.5e-7) * scale, k
     assert got[3].flat_index // target == 50
 
 

@@ -18,6 +18,7 @@ XM_FFT_ORTHO = 2
 XM_FFT_SHIFT_IN = 4
 XM_FFT_SHIFT_OUT = 8
 XM_AMAX_VALUE_ONLY = 16
+XM_AMAX_GLOBAL_KEY = 32
 
 XM_ERR_INVALID_ARG = -1
 XM_ERR_UNSUPPORTED_N = -2
@@ -50,7 +51,10 @@ SIGNATURES = {
     "xm_baseline_als": (_i, [_p, _i, _l, _i, ctypes.c_double, ctypes.c_double, _i, _p, _p, _l, _i, _p]),
     "xm_gather_row_c128": (_i, [_p, _l, _i, _p, _i, _p, _i, _p]),
     "xm_pipeline_fused": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
-    "xm_row_l1": (_i, [_p, _l, _p, _l, _i, _i, _p, _i, _p]),
+    "xm_pipeline_fused_ramp": (_i, [_p, _l, _p, _p, ctypes.c_double, ctypes.c_double, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
+    "xm_pipeline_ramp_native": (_i, [_p, _l, _i, _i, _i, _u, _i]),
+    "xm_row_l1": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "xm_argmax_key_take": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _i, _p]),
     "xm_phase_table": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p, _i]),
     "xm_solver_create": (_p, [_p, _p, _i, ctypes.c_double, _i, _i, _i]),
     "xm_solver_destroy": (None, [_p]),

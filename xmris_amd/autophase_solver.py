@@ -163,7 +163,7 @@ class NativeObjective:
             pass
 
 
-def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
+def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None):
     """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
     run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective
     values, objectives vectorised over host cores), the final L-BFGS-B polish is scipy's, exactly as
@@ -174,6 +174,8 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
 
     t0 = time.perf_counter()
     obj = NativeObjective(sl, coords, pivot, target_idx, index_width, method)
+    if threads is not None:  # several searches in flight share the host's cores
+        obj.set_threads(max(1, int(threads)))
     rc, x, fun, nfev, nit = obj.de(p0_only)  # worker pool spins for the duration of the generations
     t1 = time.perf_counter()
     # the polish's isolated evaluations below run serially (the pool is parked outside xm_solver_de)
@@ -191,7 +193,7 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only):
 
 
 def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, index_width: int,
-          method: str = "acme", p0_only: bool = False, disp: bool = False, engine: str = "native"):
+          method: str = "acme", p0_only: bool = False, disp: bool = False, engine: str = "native", threads=None):
     """phasing.py:257-287.  Returns (p0, p1, OptimizeResult).  engine="native" (default) runs the
     optimiser's generations in libxmris_hip.so; engine="scipy" calls scipy's driver with the numpy
     objectives above (the reference's own route, ~15x slower; kept for cross-checks)."""
@@ -202,7 +204,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     if method not in METHODS:
         raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
     if engine == "native" and len(sl) >= 2:
-        opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only)
+        opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads)
         return float(opt.x[0]), (float(opt.x[1]) if not p0_only else 0.0), opt
     if method == "acme":
         fn, args = acme_score, (sl, coords, pivot)

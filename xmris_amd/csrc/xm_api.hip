@@ -128,6 +128,72 @@ int xm_table_get(int kind, int n, int m, int dtype, xm_table_gen gen, const void
   return XM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-queue counters of the persistent kernels that hand out rows dynamically: a ring of {head, done} pairs per
+// device, zeroed once; every launch takes the next slot and its last workgroup leaves the pair zero again.  A slot
+// comes round again after 1024 launches on the device -- far more than can be in flight at once.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kQueueSlots = 1024, kQueueStride = 16;  // 64 bytes per slot
+static unsigned* g_queue_base[16] = {nullptr};
+static unsigned g_queue_next[16] = {0};
+
+int xm_queue_slot(unsigned** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(XM_ERR_INVALID_ARG, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_queue_base[dev]) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, kQueueSlots * kQueueStride * sizeof(unsigned)));
+    HIP_TRY(hipMemset(p, 0, kQueueSlots * kQueueStride * sizeof(unsigned)));
+    g_queue_base[dev] = (unsigned*)p;
+  }
+  *out = g_queue_base[dev] + (size_t)(g_queue_next[dev]++ % kQueueSlots) * kQueueStride;
+  return XM_OK;
+}
+
+// e^{i (phase0 + dphase k)} for the kernels that take the phase as a table
+template <class T>
+__global__ void k_ramp_table(Cx<T>* table, int n, double phase0, double dphase) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    double sn, cs;
+    sincos(phase0 + dphase * (double)k, &sn, &cs);
+    table[k] = mk<T>((T)cs, (T)sn);
+  }
+}
+
+int xm_ramp_table_async(void* table, int n, double phase0, double dphase, int dtype, hipStream_t st) {
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_ramp_table<float>, dim3((n + 255) / 256), dim3(256), 0, st, (Cx<float>*)table, n, phase0, dphase);
+  else
+    hipLaunchKernelGGL(k_ramp_table<double>, dim3((n + 255) / 256), dim3(256), 0, st, (Cx<double>*)table, n, phase0, dphase);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// The library keys its table cache, occupancy caches and scratch on the CURRENT device; the caller's buffers decide
+// which device that has to be.  Entry points that launch kernels make the device of their (device-memory) input
+// current for the duration of the call.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(const void* dev_ptr) {
+    if (!dev_ptr) return;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dev_ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    if (at.type != hipMemoryTypeDevice) return;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (cur != at.device && hipSetDevice(at.device) == hipSuccess) prev = cur;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 static int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   const long long cap = 256LL * 16;  // 256 CUs x 16 workgroups, grid-stride the rest
@@ -156,18 +222,29 @@ int xm_clear_cache(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_tables) (void)hipFree(kv.second);
   g_tables.clear();
+  for (int d = 0; d < 16; ++d) {
+    if (g_queue_base[d]) (void)hipFree(g_queue_base[d]);  // NB: tables and rings are freed with their device current
+    g_queue_base[d] = nullptr;
+  }
   return XM_OK;
 }
 
 int xm_fft_supported(int n, int dtype) { return xm_supported(n, dtype) ? 1 : 0; }
 
 int xm_plan_prepare(int n, int dtype) {
-  // run the pipeline on an empty batch: builds and caches every table the length needs
+  // run the pipeline on an empty batch: the dispatch makes the same decisions as a real call of that geometry and
+  // builds + caches the tables of the kernel it picks (twiddles of that kernel's plan, half-length rotation, chirps)
   if (!xm_supported(n, dtype)) return fail(XM_ERR_UNSUPPORTED_N, "unsupported length " + std::to_string(n));
-  // tables are created lazily inside launch_plan even for n_batch == 0
-  if (dtype == XM_C64)
-    return xm_pipeline_f32(nullptr, n, nullptr, nullptr, nullptr, 0, n, n, 0, 0, nullptr, nullptr, nullptr);
-  return xm_pipeline_f64(nullptr, n, nullptr, nullptr, nullptr, 0, n, n, 0, 0, nullptr, nullptr, nullptr);
+  int rc = XM_OK;
+  // no zero fill, and (even n) the 2x end zero fill of n/2 samples that the hot path runs
+  const int n_ins[2] = {n, n / 2};
+  for (int i = 0; i < (n % 2 == 0 && n >= 4 ? 2 : 1) && rc == XM_OK; ++i) {
+    const unsigned fl = XM_FFT_ORTHO | XM_FFT_SHIFT_OUT;
+    rc = dtype == XM_C64
+             ? xm_pipeline_f32(nullptr, n_ins[i], nullptr, nullptr, nullptr, nullptr, 0, n_ins[i], n, 0, fl, nullptr, nullptr, nullptr)
+             : xm_pipeline_f64(nullptr, n_ins[i], nullptr, nullptr, nullptr, nullptr, 0, n_ins[i], n, 0, fl, nullptr, nullptr, nullptr);
+  }
+  return rc;
 }
 
 int xm_zero_fill(const void* in, void* out, int64_t n_batch, int n_in, int n_out, int pad_left, int dtype,
@@ -179,6 +256,7 @@ int xm_zero_fill(const void* in, void* out, int64_t n_batch, int n_in, int n_out
   if (n_batch == 0) return XM_OK;
   const long long total = (long long)n_batch * n_out;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_zero_fill<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
                        (Cx<float>*)out, (long long)n_batch, n_in, n_out, pad_left);
@@ -196,6 +274,7 @@ int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, i
   if (n_batch == 0) return XM_OK;
   const long long total = (long long)n_batch * n;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_apodize<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
                        (Cx<float>*)out, (const float*)window, (long long)n_batch, n);
@@ -214,6 +293,7 @@ int xm_phase_apply(const void* in, void* out, const void* phase_table, int64_t n
   if (n_batch == 0) return XM_OK;
   const long long total = (long long)n_batch * n;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_phase<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
                        (Cx<float>*)out, (const Cx<float>*)phase_table, (long long)n_batch, n);
@@ -233,6 +313,7 @@ int xm_roll(const void* in, void* out, int64_t n_batch, int n, int shift, int dt
   if (shift < 0) shift += n;
   const long long total = (long long)n_batch * n;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_roll<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const Cx<float>*)in,
                        (Cx<float>*)out, (long long)n_batch, n, shift);
@@ -250,6 +331,7 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
   if (!absmax2 || !argidx) return fail(XM_ERR_INVALID_ARG, "absmax_rows: null outputs");
   if (n_batch == 0) return XM_OK;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   const int grid = (int)(n_batch < 65536 * 4 ? n_batch : 65536 * 4);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_absmax_rows<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in,
@@ -262,21 +344,26 @@ int xm_absmax_rows(const void* in, int64_t n_batch, int n, void* absmax2, int32_
 }
 
 int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int pad_left,
-              void* norm, int dtype, void* stream) {
+              int sub_step, void* norm, uint64_t* key, int dtype, void* stream) {
   int rc = check_common(in, n_batch, n_in, dtype);
   if (rc) return rc;
-  if (!norm || pad_left < 0 || in_row_stride < n_in) return fail(XM_ERR_INVALID_ARG, "row_l1: bad arguments");
+  if ((!norm && !key) || pad_left < 0 || in_row_stride < n_in || sub_step < 1)
+    return fail(XM_ERR_INVALID_ARG, "row_l1: bad arguments");
+  if (key && (dtype != XM_C64 || n_batch > 0xffffffffLL))
+    return fail(XM_ERR_INVALID_ARG, "row_l1: the arg-max key needs complex64 and fewer than 2^32 rows");
   if (n_batch == 0) return XM_OK;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   const int64_t want = (n_batch + 3) / 4;  // four rows (waves) per workgroup
   const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_row_l1<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in, (long long)in_row_stride,
-                       (const float*)window, (long long)n_batch, n_in, pad_left, (float*)norm);
+                       (const float*)window, (long long)n_batch, n_in, pad_left, sub_step, (float*)norm,
+                       (unsigned long long*)key);
   else
     hipLaunchKernelGGL(k_row_l1<double>, dim3(grid), dim3(256), 0, st, (const Cx<double>*)in,
-                       (long long)in_row_stride, (const double*)window, (long long)n_batch, n_in, pad_left,
-                       (double*)norm);
+                       (long long)in_row_stride, (const double*)window, (long long)n_batch, n_in, pad_left, sub_step,
+                       (double*)norm, (unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
   return XM_OK;
 }
@@ -287,12 +374,30 @@ int xm_argmax_reduce(const void* absmax2, const int32_t* argidx, int64_t n_batch
     return fail(XM_ERR_INVALID_ARG, "argmax_reduce: null pointer or empty batch");
   if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(absmax2);
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_argmax_final<float>, dim3(1), dim3(1024), 0, st, (const float*)absmax2, argidx,
                        (long long)n_batch, n, (float*)out_max2, (long long*)out_flat);
   else
     hipLaunchKernelGGL(k_argmax_final<double>, dim3(1), dim3(1024), 0, st, (const double*)absmax2, argidx,
                        (long long)n_batch, n, (double*)out_max2, (long long*)out_flat);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+int xm_argmax_key_take(uint64_t* key, int n_per_row, void* out_max2, int64_t* out_flat, const void* in,
+                       int64_t in_row_stride, int n_in, void* out_row, int dtype, void* stream) {
+  if (!key || !out_max2 || !out_flat || n_per_row < 1) return fail(XM_ERR_INVALID_ARG, "argmax_key_take: null pointer");
+  if (in && (!out_row || n_in < 1 || in_row_stride < n_in)) return fail(XM_ERR_INVALID_ARG, "argmax_key_take: bad row geometry");
+  if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(key);
+  if (dtype == XM_C64)
+    hipLaunchKernelGGL(k_key_take<float>, dim3(1), dim3(1024), 0, st, (unsigned long long*)key, n_per_row, (float*)out_max2,
+                       (long long*)out_flat, (const Cx<float>*)in, (long long)in_row_stride, n_in, (Cx<double>*)out_row);
+  else
+    hipLaunchKernelGGL(k_key_take<double>, dim3(1), dim3(1024), 0, st, (unsigned long long*)key, n_per_row, (float*)out_max2,
+                       (long long*)out_flat, (const Cx<double>*)in, (long long)in_row_stride, n_in, (Cx<double>*)out_row);
   HIP_TRY(hipGetLastError());
   return XM_OK;
 }
@@ -305,12 +410,14 @@ int64_t xm_baseline_als_workspace_bytes(int64_t n_batch, int n) {
 int xm_baseline_als(const void* in, int is_complex, int64_t n_batch, int n, double lam, double p, int n_iter, void* out,
                     void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
   if ((!in || !out || !workspace) && n_batch > 0) return fail(XM_ERR_INVALID_ARG, "baseline_als: null pointer");
-  if (n_batch < 0 || n < 3 || n_iter < 1) return fail(XM_ERR_INVALID_ARG, "baseline_als: needs n >= 3, n_iter >= 1");
+  // n == 3: the band of D'D has no interior rows and the kernel's hard-coded ends would overlap
+  if (n_batch < 0 || n < 4 || n_iter < 1) return fail(XM_ERR_INVALID_ARG, "baseline_als: needs n >= 4, n_iter >= 1");
   if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
   if (workspace_bytes < xm_baseline_als_workspace_bytes(n_batch, n))
     return fail(XM_ERR_INVALID_ARG, "baseline_als: workspace too small (see xm_baseline_als_workspace_bytes)");
   if (n_batch == 0) return XM_OK;
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   const long long plane = (long long)n_batch * n;
   double* yt = (double*)workspace;
   double *zt = yt + plane, *l1t = yt + 2 * plane, *l2t = yt + 3 * plane, *vt = yt + 4 * plane;
@@ -341,6 +448,7 @@ int xm_gather_row_c128(const void* in, int64_t in_row_stride, int n_in, const in
     return fail(XM_ERR_INVALID_ARG, "gather_row: null pointer or bad geometry");
   if (dtype != XM_C64 && dtype != XM_C128) return fail(XM_ERR_INVALID_ARG, "bad dtype");
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   const int grid = (n_in + 255) / 256;
   if (dtype == XM_C64)
     hipLaunchKernelGGL(k_gather_row<float>, dim3(grid), dim3(256), 0, st, (const Cx<float>*)in,
@@ -352,27 +460,54 @@ int xm_gather_row_c128(const void* in, int64_t in_row_stride, int n_in, const in
   return XM_OK;
 }
 
-int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const void* window,
-                      const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
-                      void* absmax2, int32_t* argidx, int dtype, void* stream) {
+static int pipeline_common(const void* in, int64_t in_row_stride, void* out, const void* window,
+                           const void* phase_table, const double* ramp, int64_t n_batch, int n_in, int n_out,
+                           int pad_left, unsigned flags, void* absmax2, int32_t* argidx, int dtype, void* stream) {
   int rc = check_common(in, n_batch, n_out, dtype);
   if (rc) return rc;
   if (n_in < 1 || pad_left < 0 || pad_left + n_in > n_out || in_row_stride < n_in)
     return fail(XM_ERR_INVALID_ARG, "pipeline: bad zero-fill geometry or row stride");
-  if ((absmax2 == nullptr) != (argidx == nullptr))
+  if (flags & XM_AMAX_GLOBAL_KEY) {
+    if (!absmax2 || n_batch > 0xffffffffLL ||
+        !xm_pipeline_ramp_native(in, in_row_stride, n_in, n_out, pad_left, flags & ~(XM_AMAX_GLOBAL_KEY | XM_AMAX_VALUE_ONLY), dtype))
+      return fail(XM_ERR_INVALID_ARG, "pipeline: XM_AMAX_GLOBAL_KEY needs a key and a geometry of xm_pipeline_ramp_native");
+  } else if ((absmax2 == nullptr) != (argidx == nullptr))
     return fail(XM_ERR_INVALID_ARG, "pipeline: absmax2 and argidx must be given together");
   if (!out && !absmax2) return fail(XM_ERR_INVALID_ARG, "pipeline: nothing to produce");
   if (out == in) return fail(XM_ERR_INVALID_ARG, "pipeline: in-place operation is not supported");
-  if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT | XM_AMAX_VALUE_ONLY))
+  if (ramp && !out) return fail(XM_ERR_INVALID_ARG, "pipeline: a phase ramp needs an output");
+  if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT | XM_AMAX_VALUE_ONLY | XM_AMAX_GLOBAL_KEY))
     return fail(XM_ERR_INVALID_ARG, "pipeline: unknown flag bits");
   if (!xm_supported(n_out, dtype))
     return fail(XM_ERR_UNSUPPORTED_N, "no in-LDS plan for length " + std::to_string(n_out));
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
   if (dtype == XM_C64)
-    return xm_pipeline_f32(in, in_row_stride, out, window, phase_table, n_batch, n_in, n_out, pad_left, flags,
+    return xm_pipeline_f32(in, in_row_stride, out, window, phase_table, ramp, n_batch, n_in, n_out, pad_left, flags,
                            absmax2, argidx, st);
-  return xm_pipeline_f64(in, in_row_stride, out, window, phase_table, n_batch, n_in, n_out, pad_left, flags,
+  return xm_pipeline_f64(in, in_row_stride, out, window, phase_table, ramp, n_batch, n_in, n_out, pad_left, flags,
                          absmax2, argidx, st);
+}
+
+int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const void* window,
+                      const void* phase_table, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                      void* absmax2, int32_t* argidx, int dtype, void* stream) {
+  return pipeline_common(in, in_row_stride, out, window, phase_table, nullptr, n_batch, n_in, n_out, pad_left, flags,
+                         absmax2, argidx, dtype, stream);
+}
+
+int xm_pipeline_fused_ramp(const void* in, int64_t in_row_stride, void* out, const void* window, double phase0,
+                           double dphase, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                           void* absmax2, int32_t* argidx, int dtype, void* stream) {
+  const double ramp[2] = {phase0, dphase};
+  return pipeline_common(in, in_row_stride, out, window, nullptr, ramp, n_batch, n_in, n_out, pad_left, flags, absmax2,
+                         argidx, dtype, stream);
+}
+
+int xm_pipeline_ramp_native(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags,
+                            int dtype) {
+  if (dtype != XM_C64 || n_in < 1 || pad_left < 0 || pad_left + n_in > n_out) return 0;
+  return xm_ramp_native_f32(in, in_row_stride, n_in, n_out, pad_left, flags);
 }
 
 int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype, void* stream) {

@@ -15,6 +15,8 @@
 #pragma once
 #include "xm_dft.h"
 
+#include <type_traits>
+
 // LDS rows are padded by one element every 128 bytes: 16 x 8 B (c64), 8 x 16 B (c128 or a two-lane
 // c64 pair), 4 x 32 B (two-lane c128).
 constexpr int xm_pad_shift(int elem_bytes) { return elem_bytes <= 8 ? 4 : (elem_bytes == 16 ? 3 : 2); }
@@ -71,6 +73,7 @@ struct FftPlan {
 // Twiddles are scalar complex (Cx<S>) even when the data is two-lane (Cx<V>, S = ScalarOf<V>).
 template <class S, class PL>
 struct GlobalTw {  // every stage from the (L2-resident) global table
+  static constexpr bool kHasR0 = false;
   const Cx<S>* __restrict__ tw;
   template <int ST, int U, int R1>
   XM_DEV Cx<S> get(int k) const {
@@ -78,9 +81,12 @@ struct GlobalTw {  // every stage from the (L2-resident) global table
   }
 };
 
-template <class S, class PL>
+// R0: the last stage also multiplies its input r = 0 (a per-thread unit factor folded into the last stage's
+// twiddles, e.g. the per-thread part of a linear output phase: see HotTw::fold)
+template <class S, class PL, bool R0 = false>
 struct HotTw {  // middle stages from an LDS copy of the table (or the global table when that copy would be
                 // larger than 8 KiB), last stage from per-thread registers
+  static constexpr bool kHasR0 = R0;
   static constexpr int K = PL::K;
   static constexpr int RL = PL::radix(K - 1);
   static constexpr int NREG = (K > 1) ? (PL::P / RL) * (RL - 1) : 1;
@@ -89,6 +95,16 @@ struct HotTw {  // middle stages from an LDS copy of the table (or the global ta
   static constexpr int mid_lds_size() { return mid_in_lds() ? mid_size() : 0; }
   const Cx<S>* mid;  // mid_size() entries: LDS copy or the global table itself
   Cx<S> reg[NREG];
+  Cx<S> r0[R0 ? (K > 1 ? PL::P / RL : 1) : 1];  // R0: twiddle of input r = 0 of each last-stage butterfly
+  // multiply every last-stage twiddle (and the implicit 1 of input r = 0) by the unit factor f: the transform's
+  // outputs of this thread all come out multiplied by f, for one extra complex multiply per butterfly
+  XM_DEV void fold(Cx<S> f) {
+    static_assert(R0, "fold needs the r = 0 twiddle slot");
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) reg[i] = reg[i] * f;
+#pragma unroll
+    for (int u = 0; u < (K > 1 ? PL::P / RL : 1); ++u) r0[u] = f;
+  }
   // thread t loads its last-stage twiddles: butterfly b = t + NT*u, input r -> table[(r-1)*Ns + b]
   XM_DEV void load(const Cx<S>* __restrict__ tw, int t) {
     if constexpr (K > 1) {
@@ -141,8 +157,16 @@ struct BlockFFT {
     }
   }
 
+  template <class TW, class = void>
+  struct has_r0 : std::false_type {};
+  template <class TW>
+  struct has_r0<TW, typename std::enable_if<TW::kHasR0>::type> : std::true_type {};
+
+  // `t0`: the butterfly (column) index this thread takes in stage 0 -- v[q] = x[t0 + NT*q] on entry.  Stage 0
+  // has no twiddles and scatters its outputs by address, so any bijection thread -> column works there; every
+  // later stage (and the result) uses the strided layout of `t`.
   template <int ST, int U, class TW>
-  XM_DEV static void butterflies(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
+  XM_DEV static void butterflies(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t, int t0) {
     constexpr int R = PL::radix(ST);
     constexpr int Ns = PL::ns(ST);
     constexpr int PR = P / R;
@@ -151,10 +175,11 @@ struct BlockFFT {
       Cx<V> a[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) a[r] = v[U + PR * r];
-      const int b = t + NT * U;
+      const int b = (ST == 0 ? t0 : t) + NT * U;
       if constexpr (ST > 0) {
         constexpr bool full = (Ns * R == N);  // last stage: b < Ns always
         const int k = full ? b : (b % Ns);
+        if constexpr (last && has_r0<TW>::value) a[0] = a[0] * tw.r0[U];
         twiddle_row<ST, U, 1, R>(a, tw, k);
       }
       Dft<V, R>::run(a);
@@ -172,15 +197,22 @@ struct BlockFFT {
           for (int r = 0; r < R; ++r) lds[xm_pad<SH>(o + r * Ns)] = a[r];
         }
       }
-      butterflies<ST, U + 1>(v, lds, tw, t);
+      butterflies<ST, U + 1>(v, lds, tw, t, t0);
     }
   }
 
-  template <int ST, class TW>
-  XM_DEV static void stage(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
+  struct NoHook {
+    XM_DEV void operator()() const {}
+  };
+
+  // `hook` runs once per transform, in front of the first barrier of the LAST exchange (plans with K >= 2): whatever
+  // it writes to LDS is visible to every thread when run() returns, at no extra barrier
+  template <int ST, class TW, class HOOK>
+  XM_DEV static void stage(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t, int t0, const HOOK& hook) {
     constexpr bool last = (ST == K - 1);
-    butterflies<ST, 0>(v, lds, tw, t);
+    butterflies<ST, 0>(v, lds, tw, t, t0);
     if constexpr (!last) {
+      if constexpr (ST == K - 2) hook();
       __syncthreads();
       if constexpr (PL::pow2()) {
         const Cx<V>* rp = lds + xm_pad<SH>(t);
@@ -191,7 +223,7 @@ struct BlockFFT {
         for (int q = 0; q < P; ++q) v[q] = lds[xm_pad<SH>(t + NT * q)];
       }
       __syncthreads();
-      stage<ST + 1>(v, lds, tw, t);
+      stage<ST + 1>(v, lds, tw, t, t0, hook);
     }
   }
 
@@ -199,10 +231,19 @@ struct BlockFFT {
   // All threads of the workgroup must call it (it contains workgroup barriers).
   template <class TW>
   XM_DEV static void run(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t) {
-    stage<0>(v, lds, tw, t);
+    stage<0>(v, lds, tw, t, t, NoHook{});
+  }
+  // stage-0 columns remapped: v[q] = x[t0 + NT*q] on entry (see butterflies)
+  template <class TW>
+  XM_DEV static void run_cols(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t, int t0) {
+    stage<0>(v, lds, tw, t, t0, NoHook{});
+  }
+  template <class TW, class HOOK>
+  XM_DEV static void run_cols(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t, int t0, const HOOK& hook) {
+    stage<0>(v, lds, tw, t, t0, hook);
   }
   XM_DEV static void run(Cx<V> (&v)[P], Cx<V>* lds, const Cx<S>* __restrict__ tw, int t) {
     GlobalTw<S, PL> g{tw};
-    stage<0>(v, lds, g, t);
+    stage<0>(v, lds, g, t, t, NoHook{});
   }
 };

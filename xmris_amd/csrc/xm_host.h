@@ -3,6 +3,7 @@
 #include "../../include/xmris_hip.h"
 #include "xm_common.h"
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,10 +32,45 @@ bool xm_has_pow2_plan(int n, int dtype);
 int xm_bluestein_m(int n);
 bool xm_supported(int n, int dtype);
 
-// defined in xm_launch_f32.hip / xm_launch_f64.hip
+// defined in xm_launch_f32.hip / xm_launch_f64.hip.  `ramp`: nullptr, or {phase0, dphase} in radians -- the output is
+// multiplied by e^{i (phase0 + dphase k)}, k = output index (then `phase` must be nullptr)
 int xm_pipeline_f32(const void* in, int64_t in_stride, void* out, const void* window, const void* phase,
-                    int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags, void* absmax2,
-                    int32_t* argidx, hipStream_t st);
+                    const double* ramp, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                    void* absmax2, int32_t* argidx, hipStream_t st);
 int xm_pipeline_f64(const void* in, int64_t in_stride, void* out, const void* window, const void* phase,
-                    int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags, void* absmax2,
-                    int32_t* argidx, hipStream_t st);
+                    const double* ramp, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                    void* absmax2, int32_t* argidx, hipStream_t st);
+// 1 when a geometry has a kernel that applies the ramp natively (no table is built), else 0
+int xm_ramp_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
+
+// {head, done} counter pair (zero) for one launch of a persistent kernel that hands out rows dynamically; the
+// kernel's last workgroup leaves it zero again.  Slots come from a per-device ring of 1024.
+int xm_queue_slot(unsigned** out);
+
+// e^{i (phase0 + dphase k)}, k < n, into `table` (device, storage precision of `dtype`), fp64 sincos per entry
+int xm_ramp_table_async(void* table, int n, double phase0, double dphase, int dtype, hipStream_t st);
+
+// Grid of a persistent kernel = CUs x resident workgroups per CU.  The occupancy query and the dynamic-LDS opt-in
+// run once per kernel instantiation and device, under a lock (the launchers are re-entrant).
+struct XmResidency {
+  std::mutex mu;
+  int blocks[16] = {0};
+};
+template <class K>
+int xm_resident_blocks(XmResidency& r, K kern, int nt, size_t lds, int* out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return xm_fail(XM_ERR_INVALID_ARG, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (r.blocks[dev] == 0) {
+    if (lds > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nt, lds));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (per_cu < 1) per_cu = 1;
+    r.blocks[dev] = per_cu * cus;
+  }
+  *out = r.blocks[dev];
+  return XM_OK;
+}

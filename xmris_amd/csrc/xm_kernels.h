@@ -11,6 +11,9 @@
 
 #include <type_traits>
 
+#define XM_KEY_SLOTS 64
+#define XM_KEY_STRIDE 16  // 64-bit words between partial keys (128 bytes)
+
 template <class T>
 struct PipeArgs {
   const Cx<T>* in;
@@ -29,14 +32,38 @@ struct PipeArgs {
   int inverse;
   int amax_value_only;    // skip the first-index scan (argidx written as 0)
   T scale;
+  // Linear output phase e^{i (a + b k)} (k = output index after the roll) in factorised form, for kernels whose
+  // output index is (wave-uniform base_q) + 2t + (0 | 1): ramp_c[2q], ramp_c[2q+1] = e^{i (a + b base_q)} (re, im),
+  // ramp_e = e^{i b} (fp64 on the host, rounded once), ramp_db = b; the per-thread factor e^{i b 2t} is computed
+  // in fp64 by the kernel once per launch.  use_ramp != 0 selects it (the table pointer is unused).
+  int use_ramp;
+  int stagger;            // experimental: second half of the grid starts `stagger` x 64 x 127 cycles late
+  unsigned* queue;        // persistent kernels with dynamic row hand-out: {head, done} counters, both 0 at launch
+  // XM_AMAX_GLOBAL_KEY (complex64, value-only maxima): instead of per-row outputs every wave keeps the best
+  // (max |X|^2, row) of the rows it transforms and merges it into this ONE 64-bit key with a single atomic max when
+  // it leaves: key = float bits << 32 | (0xffffffff - row), i.e. larger value first, then the lower row.  The key is
+  // kept in XM_KEY_SLOTS partial keys on cache lines of their own (slot = workgroup mod XM_KEY_SLOTS; thousands of
+  // waves leave a kernel within microseconds and one address takes ~90 atomics per microsecond), all zero at launch;
+  // k_key_take merges and clears them.
+  unsigned long long* gkey;
+  double ramp_db;
+  T ramp_e[2];
+  T ramp_c[32];
 };
 
-// ---- (value, index) arg-max helpers: larger value wins, ties -> smaller index -------------------
+// ---- (value, index) arg-max helpers: larger value wins, ties -> smaller index; a NaN outranks every number
+// (np.argmax returns the first NaN, phasing.py:229), NaN against NaN -> smaller index ------------------------
 template <class T>
 XM_DEV void amax_take(T& bv, int& bi, T v, int i) {  // branch-free
-  const bool take = (v > bv) | ((v == bv) & (i < bi));
+  const bool vn = v != v, bn = bv != bv;
+  const bool take = (v > bv) | ((v == bv) & (i < bi)) | (vn & !bn) | (vn & bn & (i < bi));
   bv = take ? v : bv;
   bi = take ? i : bi;
+}
+// fmax drops NaNs: a thread-local maximum that is still at its start value -1 saw nothing but NaNs
+template <class T>
+XM_DEV T amax_nan_if_unset(T bv) {
+  return bv < T(0) ? T(__builtin_nan("")) : bv;
 }
 
 template <class T>
@@ -70,9 +97,10 @@ XM_DEV unsigned wave_reduce_u32(unsigned v) {
 
 // (max value, first index) over the 64 lanes of a wave; result uniform across the wave
 XM_DEV void wave_amax(float& bv, int& bi) {
-  const unsigned key = __float_as_uint(bv);  // bv >= 0 (a squared magnitude) or -1 for "nothing"
+  // bv >= 0 (a squared magnitude), -1 for "nothing", or a (positive quiet) NaN, whose bit pattern outranks every number
+  const unsigned key = bv != bv ? 0x7fc00000u : __float_as_uint(bv);
   const unsigned kmax = wave_reduce_u32<true>(bv < 0.f ? 0u : key);
-  const unsigned cand = (bv >= 0.f && key == kmax) ? (unsigned)bi : 0xffffffffu;
+  const unsigned cand = (!(bv < 0.f) && key == kmax) ? (unsigned)bi : 0xffffffffu;
   bi = (int)wave_reduce_u32<false>(cand);
   bv = __uint_as_float(kmax);
 }
@@ -384,13 +412,15 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         T hv = T(-1);
 #pragma unroll
         for (int q = 0; q < P; ++q) hv = fmax(hv, h[q].re * h[q].re + h[q].im * h[q].im);
+        hv = amax_nan_if_unset(hv);
+        const bool all_nan = hv != hv;
         int hi = 0;
         if (!A.amax_value_only) {  // wave-uniform
           hi = 0x7fffffff;
 #pragma unroll
           for (int q = 0; q < P; ++q) {
             const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2 + odd);
-            hi = min(hi, (h[q].re * h[q].re + h[q].im * h[q].im) == hv ? k0 : 0x7fffffff);
+            hi = min(hi, (((h[q].re * h[q].re + h[q].im * h[q].im) == hv) | all_nan) ? k0 : 0x7fffffff);
           }
         }
         amax_take(bv, bi, hv, hi);
@@ -466,6 +496,8 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         mag2(q, me, mo);
         bv = fmax(bv, fmax(me, mo));
       }
+      bv = amax_nan_if_unset(bv);
+      const bool all_nan = bv != bv;  // then every index of this thread qualifies
       int bi = 0;
       if (!CVO && !A.amax_value_only) {  // wave-uniform (CVO: compiled out)
         bi = 0x7fffffff;
@@ -474,8 +506,8 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
           const int k0 = (int)(((2u * NT * q + sh) & (N - 1u)) + t2);
           T me, mo;
           mag2(q, me, mo);
-          bi = min(bi, me == bv ? k0 : 0x7fffffff);
-          bi = min(bi, mo == bv ? k0 + 1 : 0x7fffffff);
+          bi = min(bi, ((me == bv) | all_nan) ? k0 : 0x7fffffff);
+          bi = min(bi, ((mo == bv) | all_nan) ? k0 + 1 : 0x7fffffff);
         }
       }
       if constexpr (PACKED && NT > XM_WAVE) {
@@ -617,14 +649,17 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
         b0 = fmax(b0, m2.x);
         b1 = fmax(b1, m2.y);
       }
+      b0 = amax_nan_if_unset(b0);
+      b1 = amax_nan_if_unset(b1);
+      const bool nan0 = b0 != b0, nan1 = b1 != b1;
       int i0 = 0x7fffffff, i1 = 0x7fffffff;
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         int k = tt + NT * q + osh;
         if (k >= N) k -= N;
         const V m2 = v[q].re * v[q].re + v[q].im * v[q].im;
-        i0 = min(i0, m2.x == b0 ? k : 0x7fffffff);
-        i1 = min(i1, m2.y == b1 ? k : 0x7fffffff);
+        i0 = min(i0, ((m2.x == b0) | nan0) ? k : 0x7fffffff);
+        i1 = min(i1, ((m2.y == b1) | nan1) ? k : 0x7fffffff);
       }
       amax_reduce_store<T, NT>(b0, i0, tt, true, s0, A.absmax2, A.argidx, red_v, red_i);
       amax_reduce_store<T, NT>(b1, i1, tt, has1, has1 ? s1 : s0, A.absmax2, A.argidx, red_v + NT / XM_WAVE + 1,
@@ -727,12 +762,14 @@ __global__ __launch_bounds__(PL::NT, (fft1_waves<T, PL>())) void k_fft1(PipeArgs
       T bv = T(-1);
 #pragma unroll
       for (int q = 0; q < P; ++q) bv = fmax(bv, v[q].re * v[q].re + v[q].im * v[q].im);
+      bv = amax_nan_if_unset(bv);
+      const bool all_nan = bv != bv;
       int bi = 0x7fffffff;
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         int k = tt + NT * q + osh;
         if (k >= N) k -= N;
-        bi = min(bi, (v[q].re * v[q].re + v[q].im * v[q].im) == bv ? k : 0x7fffffff);
+        bi = min(bi, (((v[q].re * v[q].re + v[q].im * v[q].im) == bv) | all_nan) ? k : 0x7fffffff);
       }
       amax_reduce_store<T, NT>(bv, bi, tt, true, s, A.absmax2, A.argidx, red_v, red_i);
     }
@@ -1047,7 +1084,7 @@ __global__ void k_roll(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, lo
 template <class T>
 __global__ void k_gather_row(const Cx<T>* __restrict__ in, long long in_stride, int n_in,
                              const long long* __restrict__ flat, int n_per_row, Cx<double>* __restrict__ out) {
-  const long long row = flat[0] / n_per_row;
+  const long long row = flat[0] / n_per_row;  // the launcher's caller guarantees 0 <= flat < n_batch * n_per_row
   const Cx<T>* src = in + row * in_stride;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_in; j += gridDim.x * blockDim.x)
     out[j] = mk<double>((double)src[j].re, (double)src[j].im);
@@ -1087,15 +1124,19 @@ __global__ __launch_bounds__(256) void k_absmax_rows(const Cx<T>* __restrict__ i
   }
 }
 
-// Windowed L1 norm of every FID: norm[b] = sum_j |in[b, j]| * |window[j + pad_left]|  (window == NULL: 1).
+// Windowed L1 norm of every FID: norm[b] = sum_j |in[b, j]| * |window[j + pad_left]|  (window == NULL: 1), over the
+// 1-KiB blocks (128 complex64 / 64 complex128 samples) whose index is a multiple of `sub_step` (1 = every sample).
 // sum_j |z_j| / sqrt(N) bounds every |X[k]| of the row from above and equals the peak height of a single
 // decaying resonance, so the row with the largest norm is the natural GUESS for the row that holds the global
-// arg-max (autophase's speculative schedule; the guess is verified against the true maxima afterwards).
+// arg-max (autophase's speculative schedule; the guess is verified against the true maxima afterwards, so a
+// ranking statistic is all that is needed: a regular subset of whole cache lines spread over the window's support
+// ranks rows like the full sum does and reads 1/sub_step of the bytes).
 // Streaming read, one wave per row, persistent grid.
 template <class T>
 __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, long long in_stride,
                                                  const T* __restrict__ window, long long n_batch, int n_in,
-                                                 int pad_left, T* __restrict__ norm) {
+                                                 int pad_left, int sub_step, T* __restrict__ norm,
+                                                 unsigned long long* gkey) {
   // one WAVE per row (four rows per workgroup): no LDS, no barriers, a shuffle reduction at the end of the row
   constexpr int UN = 8;  // independent 16-byte loads in flight per lane and round (read-only streaming)
   constexpr int PER = 16 / (int)sizeof(Cx<T>);  // samples per 16-byte load: 2 (complex64) or 1 (complex128)
@@ -1103,17 +1144,23 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
   const int lane = threadIdx.x & (XM_WAVE - 1);
   const long long wave = (long long)blockIdx.x * (256 / XM_WAVE) + (threadIdx.x / XM_WAVE);
   const long long nwaves = (long long)gridDim.x * (256 / XM_WAVE);
+  // vector index v (16-byte words of a row) -> the v-th word of the sampled subset: blocks of 64 words
+  // (128 complex64 samples), every sub_step-th block
+  auto word_of = [&](int v) { return sub_step <= 1 ? v : ((v >> 6) * sub_step << 6) + (v & 63); };
+  unsigned long long best = 0;  // gkey: best (norm, row) of this wave's rows, merged once at the end
   for (long long b = wave; b < n_batch; b += nwaves) {
     const Cx<T>* __restrict__ row = in + b * in_stride;
     T acc = T(0);
     if (wide) {
       const int nvec = n_in / PER;
-      for (int j0 = lane; j0 < nvec; j0 += XM_WAVE * UN) {
+      const int nblk = (nvec + 63) >> 6;
+      const int nsub = sub_step <= 1 ? nvec : (((nblk + sub_step - 1) / sub_step) << 6);  // words of the subset (upper bound)
+      for (int j0 = lane; j0 < nsub; j0 += XM_WAVE * UN) {
         Cx<T> x[UN][PER];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int j = j0 + XM_WAVE * u;
-          if (j < nvec) {
+          const int j = word_of(j0 + XM_WAVE * u);
+          if (j0 + XM_WAVE * u < nsub && j < nvec) {
             const xm_u4 raw = *reinterpret_cast<const xm_u4*>(row + (long long)j * PER);
             __builtin_memcpy(&x[u][0], &raw, 16);
           } else {
@@ -1123,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int j = (j0 + XM_WAVE * u) * PER;
+          const int j = word_of(j0 + XM_WAVE * u) * PER;
 #pragma unroll
           for (int e = 0; e < PER; ++e) {
             const T m = sqrt(x[u][e].re * x[u][e].re + x[u][e].im * x[u][e].im);
@@ -1133,6 +1180,7 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
       }
     } else {
       for (int j = lane; j < n_in; j += XM_WAVE) {
+        if (sub_step > 1 && ((j >> 7) % sub_step) != 0) continue;
         const Cx<T> x = row[j];
         const T m = sqrt(x.re * x.re + x.im * x.im);
         acc += window ? m * fabs(window[j + pad_left]) : m;
@@ -1140,8 +1188,53 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
     }
 #pragma unroll
     for (int m = XM_WAVE / 2; m >= 1; m >>= 1) acc += shfl_xor_t(acc, m);
-    if (lane == 0) norm[b] = acc;
+    if (lane == 0 && norm) norm[b] = acc;
+    if constexpr (sizeof(T) == 4) {
+      if (gkey) {
+        const unsigned bits = acc != acc ? 0x7fc00000u : __float_as_uint(acc);  // norms are >= 0: ordered like their bits
+        const unsigned long long k = ((unsigned long long)bits << 32) | (unsigned long long)(0xffffffffu - (unsigned)b);
+        best = k > best ? k : best;
+      }
+    }
   }
+  if constexpr (sizeof(T) == 4) {
+    if (gkey && lane == 0 && best != 0) atomicMax(gkey + (blockIdx.x % XM_KEY_SLOTS) * XM_KEY_STRIDE, best);
+  }
+}
+
+// Consumer of a global arg-max key (see PipeArgs::gkey): out_max2[0] = the value, out_flat[0] = row * n_per_row, and
+// the key is left zero for its next producer.  With `in`: also the winning row, upcast to complex128 (the gather of
+// k_gather_row).  ONE workgroup.
+template <class T>
+__global__ __launch_bounds__(1024) void k_key_take(unsigned long long* key, int n_per_row, float* out_max2, long long* out_flat,
+                                                    const Cx<T>* __restrict__ in, long long in_stride, int n_in,
+                                                    Cx<double>* __restrict__ out_row) {
+  __shared__ unsigned long long part[XM_KEY_SLOTS];
+  if (threadIdx.x < XM_KEY_SLOTS)
+    part[threadIdx.x] = __hip_atomic_load(key + threadIdx.x * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  unsigned long long k = 0;
+  for (int i = 0; i < XM_KEY_SLOTS; ++i) k = part[i] > k ? part[i] : k;
+  const long long row = (long long)(0xffffffffu - (unsigned)(k & 0xffffffffu));
+  if (in) {
+    const Cx<T>* src = in + row * in_stride;
+    for (int j = threadIdx.x; j < n_in; j += blockDim.x) out_row[j] = mk<double>((double)src[j].re, (double)src[j].im);
+  }
+  if (threadIdx.x < XM_KEY_SLOTS)
+    __hip_atomic_store(key + threadIdx.x * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    out_max2[0] = __uint_as_float((unsigned)(k >> 32));
+    out_flat[0] = row * (long long)n_per_row;
+  }
+}
+
+// (value a, flat index ia) beats (b, ib): NaN outranks numbers, then the larger value, ties -> the lower index
+template <class T>
+XM_DEV bool amax_final_better(T a, long long ia, T b, long long ib) {
+  const bool an = a != a, bn = b != b;
+  if (an != bn) return an;
+  if (an) return ia < ib;
+  return a > b || (a == b && ia < ib);
 }
 
 // single workgroup: global (max, first flat index) over the per-spectrum pairs
@@ -1156,7 +1249,11 @@ __global__ __launch_bounds__(1024) void k_argmax_final(const T* __restrict__ abs
   // One workgroup, so the scan is latency bound: every thread scans the VALUES of its rows with UN
   // independent loads in flight per round and remembers the first row holding its maximum; the index
   // array is read once per thread, for that row only.
+  // np.argmax(np.abs(x)) returns the FIRST NaN when there is one (NaN compares as the maximum there): a NaN row
+  // maximum (rows whose kernels propagate NaN) outranks every number, first row wins.  Kernels that build the row
+  // maxima with fmax / integer atomics never report NaN; such rows carry their largest finite value instead.
   constexpr int UN = 16;
+  bool have_nan = false;
   for (long long b0 = threadIdx.x; b0 < n_batch; b0 += 1024 * UN) {
     T v[UN];
 #pragma unroll
@@ -1167,18 +1264,24 @@ __global__ __launch_bounds__(1024) void k_argmax_final(const T* __restrict__ abs
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long long b = b0 + 1024LL * u;
-      if (v[u] > bv) {  // strict: keeps the lowest row among equal values (rows ascend with u and b0)
+      const bool is_nan = v[u] != v[u];
+      if (is_nan ? !have_nan : (!have_nan && v[u] > bv)) {  // strict: keeps the lowest row among equal values
         bv = v[u];
         bi = b;
       }
+      have_nan = have_nan || is_nan;
     }
+  }
+  if (bi == 0x7fffffffffffffffLL && threadIdx.x == 0 && n_batch > 0) {  // nothing above -1 anywhere: row 0
+    bv = absmax2[0];
+    bi = 0;
   }
   if (bi != 0x7fffffffffffffffLL) bi = bi * (long long)n + argidx[bi];  // one index load per thread
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     T ov = shfl_xor_t(bv, m);
     long long oi = __shfl_xor(bi, m, XM_WAVE);
-    if (ov > bv || (ov == bv && oi < bi)) {
+    if (amax_final_better(ov, oi, bv, bi)) {
       bv = ov;
       bi = oi;
     }
@@ -1190,7 +1293,7 @@ __global__ __launch_bounds__(1024) void k_argmax_final(const T* __restrict__ abs
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w) {
-      if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) {
+      if (amax_final_better(red_v[w], red_i[w], bv, bi)) {
         bv = red_v[w];
         bi = red_i[w];
       }

@@ -3,8 +3,8 @@
 #include "xm_launch.inc"
 
 int xm_pipeline_f64(const void* in, int64_t in_stride, void* out, const void* window, const void* phase,
-                    int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags, void* absmax2,
-                    int32_t* argidx, hipStream_t st) {
-  return pipeline_typed(in, in_stride, out, window, phase, n_batch, n_in, n_out, pad_left, flags, absmax2, argidx,
-                        st);
+                    const double* ramp, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
+                    void* absmax2, int32_t* argidx, hipStream_t st) {
+  return pipeline_typed(in, in_stride, out, window, phase, ramp, n_batch, n_in, n_out, pad_left, flags, absmax2,
+                        argidx, st);
 }

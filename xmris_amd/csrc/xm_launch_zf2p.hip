@@ -1,0 +1,96 @@
+// Instantiation + launch of k_zf2p (xm_zf2p.h), the packed complex64 ">= 2x end zero-fill" kernel of the hot path.
+// Its own translation unit so that it compiles in parallel with the other kernels.
+#include "xm_host.h"
+#include "xm_plans.h"
+#include "xm_tables.h"
+#include "xm_zf2p.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+using T = float;
+
+template <class PL, int MODE, int OPT>
+int launch_mode(PipeArgs<T> A, hipStream_t st) {
+  const void* tw = nullptr;
+  int rc = xm_table_get(TK_TWIDDLE, PL::N, PL::NT, XM_C64, xm_gen_twiddles<PL>, nullptr, &tw);
+  if (rc) return rc;
+  A.tw = (const Cx<T>*)tw;
+  if (A.n_batch <= 0) return XM_OK;
+  constexpr bool L16 = (OPT & ZF2P_LOAD16) != 0;
+  using FFT = BlockFFT<xm_f2, PL, L16 ? xm_ilog2(2 * PL::radix(0)) : -1>;
+  const size_t lds = (size_t)FFT::lds_elems() * sizeof(Cx<xm_f2>) + (size_t)HotTw<T, PL>::mid_size() * sizeof(Cx<T>) +
+                     ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
+  static XmResidency res;
+  int resident = 0;
+  rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident);
+  if (rc) return rc;
+  const long long blocks = A.n_batch < resident ? A.n_batch : resident;
+  if constexpr ((MODE & ZF2_AMAX) != 0) {
+    // value-only maxima are accumulated with one atomic max per wave: the slots start at +0.0
+    if (A.amax_value_only && !A.gkey) HIP_TRY(hipMemsetAsync(A.absmax2, 0, (size_t)A.n_batch * sizeof(T), st));
+  }
+  if constexpr ((OPT & ZF2P_QUEUE) != 0) {
+    rc = xm_queue_slot(&A.queue);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((k_zf2p<PL, MODE, OPT>), dim3((unsigned)blocks), dim3(PL::NT), lds, st, A);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+// Write modes are HBM bound and unevenly so across workgroups: dynamic row hand-out + nontemporal stores.  The
+// arg-max-only pre-pass is instruction bound (every workgroup takes the same time per row): static stride.
+constexpr int kOptWrite = ZF2P_LOAD16 | ZF2P_NT | ZF2P_QUEUE;
+constexpr int kOptAmax = ZF2P_LOAD16;
+
+template <class PL>
+int launch_plan(PipeArgs<T> A, const double* ramp, hipStream_t st) {
+  const bool wr = A.out != nullptr, ph = A.phase != nullptr, am = A.absmax2 != nullptr;
+  if (ramp) {
+    // e^{i (a + b k)}, k = base_q + 2t (+1): the wave-uniform factors, and e^{i b} for the odd bins
+    constexpr unsigned N = 2 * PL::N;
+    for (int q = 0; q < PL::P; ++q) {
+      const unsigned base = (2u * PL::NT * q + (unsigned)A.out_shift) & (N - 1u);
+      const double a = ramp[0] + ramp[1] * (double)base;
+      A.ramp_c[2 * q] = (T)std::cos(a);
+      A.ramp_c[2 * q + 1] = (T)std::sin(a);
+    }
+    A.ramp_e[0] = (T)std::cos(ramp[1]);
+    A.ramp_e[1] = (T)std::sin(ramp[1]);
+    A.ramp_db = ramp[1];
+    A.use_ramp = 1;
+    A.phase = nullptr;
+    return am ? launch_mode<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX, kOptWrite>(A, st)
+              : launch_mode<PL, ZF2_WRITE | ZF2_RAMP, kOptWrite>(A, st);
+  }
+  if (wr && ph && am) return launch_mode<PL, ZF2_WRITE | ZF2_PHASE | ZF2_AMAX, kOptWrite>(A, st);
+  if (wr && ph) return launch_mode<PL, ZF2_WRITE | ZF2_PHASE, kOptWrite>(A, st);
+  if (wr && am) return launch_mode<PL, ZF2_WRITE | ZF2_AMAX, kOptWrite>(A, st);
+  if (wr) return launch_mode<PL, ZF2_WRITE, kOptWrite>(A, st);
+  return launch_mode<PL, ZF2_AMAX, kOptAmax>(A, st);
+}
+
+}  // namespace
+
+bool xm_zf2p_eligible(const PipeArgs<float>& A, int64_t in_stride) {
+  static const bool gen1 = getenv("XM_ZF2_GEN1") != nullptr;  // tuning switch: the first-generation kernel
+  if (gen1) return false;
+  // pair loads: every (even, odd) sample pair of a row is one aligned 16-byte word
+  return (A.pad_left % 2 == 0) && (A.n_in % 2 == 0) && (in_stride % 2 == 0) && ((reinterpret_cast<size_t>(A.in) & 15u) == 0);
+}
+
+int xm_zf2p_launch(int h, const PipeArgs<float>& A, const double* ramp, hipStream_t st) {
+  switch (h) {
+    case 512: return launch_plan<typename Zf2PlanOf<512>::type>(A, ramp, st);
+    case 1024: return launch_plan<typename Zf2PlanOf<1024>::type>(A, ramp, st);
+    case 2048: return launch_plan<typename Zf2PlanOf<2048>::type>(A, ramp, st);
+    case 4096: return launch_plan<typename PlanOf<4096>::type>(A, ramp, st);  // 256 threads x 16 points, 16.16.16
+    default: break;
+  }
+  return xm_fail(XM_ERR_UNSUPPORTED_N, "no half-length plan for " + std::to_string(h));
+}

@@ -258,10 +258,7 @@ struct Pool {
   const double* params = nullptr;  // (p0, p1) in radians per evaluation of the job
   int nchunk = 0, neval = 1, team = 1;
 
-  static Pool& get() {
-    static Pool* p = new Pool();  // intentionally leaked: workers may outlive static destruction
-    return *p;
-  }
+  bool in_use = false;  // guarded by g_pools_mu
   // task j = evaluation j / nchunk, part j % nchunk (nchunk = parts per evaluation); member id takes tasks
   // id, id + team, ... -> slot[id].sums[local]
   void run_share(int id) {
@@ -329,6 +326,14 @@ struct Pool {
   }
 };
 
+// A few pools so that several searches (independent datasets, one Python thread each) can run at the same time, each
+// with its own team.  A search owns its pool from xm_solver_pool_begin to xm_solver_pool_end ON ITS OWN THREAD
+// (t_pool): evaluations issued by any other thread (a polish, score calls from Python) never touch a team.
+constexpr int kPools = 4;
+Pool* g_pools[kPools] = {nullptr, nullptr, nullptr, nullptr};  // intentionally leaked: workers may outlive static destruction
+std::mutex g_pools_mu;
+thread_local Pool* t_pool = nullptr;
+
 double Solver::acme(double p0r, double p1r) const {
   double out;
   const double p[2] = {p0r, p1r};
@@ -338,8 +343,8 @@ double Solver::acme(double p0r, double p1r) const {
 
 void Solver::acme_batch(const double* p01r, int count, double* out) const {
   const int nn = n, nchunk = nparts();  // work units per evaluation
-  Pool& pool = Pool::get();
-  const bool par = threads > 1 && nn >= 2048 && pool.active() && pool.fits(nchunk, threads);
+  Pool* const poolp = t_pool;  // only the thread that owns a running search has one
+  const bool par = threads > 1 && nn >= 2048 && poolp && poolp->active() && poolp->fits(nchunk, threads);
   if (!par) {
     for (int e = 0; e < count; ++e) {
       double local[5];
@@ -350,6 +355,7 @@ void Solver::acme_batch(const double* p01r, int count, double* out) const {
     }
     return;
   }
+  Pool& pool = *poolp;
   // as many evaluations per hand-off as the per-member result slots hold
   const int per = std::max(1, (Pool::kMaxLocal * threads) / nchunk);
   for (int e0 = 0; e0 < count; e0 += per) {
@@ -464,19 +470,32 @@ int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, do
   return 0;
 }
 
-// One search at a time owns the pool (two Python threads may call xm_solver_de concurrently).
-static std::mutex g_search_mu;
-
+// A search takes a free pool for its duration; with every pool taken it evaluates serially.
 void xm_solver_pool_begin(int threads) {
-  g_search_mu.lock();
-  Pool& p = Pool::get();
-  p.ensure(threads - 1);
-  p.activate();
+  Pool* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    for (int i = 0; i < kPools && !p; ++i) {
+      if (!g_pools[i]) g_pools[i] = new Pool();
+      if (!g_pools[i]->in_use) {
+        p = g_pools[i];
+        p->in_use = true;
+      }
+    }
+  }
+  t_pool = p;
+  if (!p) return;
+  p->ensure(threads - 1);
+  p->activate();
 }
 
 void xm_solver_pool_end(void) {
-  Pool::get().park();
-  g_search_mu.unlock();
+  Pool* p = t_pool;
+  if (!p) return;
+  t_pool = nullptr;
+  p->park();
+  std::lock_guard<std::mutex> lk(g_pools_mu);
+  p->in_use = false;
 }
 
 }  // extern "C"

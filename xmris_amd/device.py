@@ -318,12 +318,25 @@ class FusedResult:
         self.out, self.absmax2, self.argidx = out, absmax2, argidx
 
 
+def ramp_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho: bool = True) -> bool:
+    """True when the fused kernel of this geometry applies a linear phase natively (`phase_ramp=` of
+    `pipeline_fused` then costs no table and no per-output load); otherwise callers upload a phase table."""
+    _require_device(x2)
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    return bool(_lib.load().xm_pipeline_ramp_native(x2.data_ptr(), x2.shape[1], x2.shape[1], int(n_out), int(pad_left),
+                                                    flags, _dtype_code(x2)))
+
+
 def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
                    ortho: bool = True, want_out: bool = True, want_argmax: bool = False, out=None,
-                   absmax2=None, argidx=None, argmax_value_only: bool = False):
+                   absmax2=None, argidx=None, argmax_value_only: bool = False, phase_ramp=None, global_key=None):
     """One launch of zero-fill + window + FFT(+fftshift) [+ |X|^2 arg-max] [+ phase] on
     ``x2`` = [n_batch, n_in] contiguous rows (FID axis last).  `window` / `phase_table` are
-    device tensors of the storage precision (real n_out / complex n_out) or None."""
+    device tensors of the storage precision (real n_out / complex n_out) or None.
+    `phase_ramp` = (phase0, dphase) in radians multiplies output k by e^{i (phase0 + dphase k)} instead of a
+    table (phasing.py:62-73 on a uniform axis).  `global_key` (`new_argmax_key`, geometries
+    with `ramp_native` only) receives the launch's global arg-max (value bits, row) instead of per-row outputs;
+    `argmax_key_take` decodes and clears it."""
     _require_device(x2)
     torch = _torch()
     if x2.dim() != 2 or not x2.is_contiguous():
@@ -332,14 +345,27 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
     rd = _real_dtype(x2)
     if want_out and out is None:
         out = torch.empty((nb, n_out), dtype=x2.dtype, device=x2.device)
+    if global_key is not None:
+        want_argmax, absmax2, argidx = True, global_key, global_key  # the key rides in the absmax2 slot
     if want_argmax:
         if absmax2 is None:
             absmax2 = torch.empty(nb, dtype=rd, device=x2.device)
         if argidx is None:
             argidx = torch.empty(nb, dtype=torch.int32, device=x2.device)
     flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    if global_key is not None:
+        flags |= _lib.XM_AMAX_GLOBAL_KEY | _lib.XM_AMAX_VALUE_ONLY
     if argmax_value_only:  # hint: kernels may skip the first-index scan (argidx then holds 0)
         flags |= _lib.XM_AMAX_VALUE_ONLY
+    if phase_ramp is not None:
+        if phase_table is not None or not want_out:
+            raise ValueError("phase_ramp excludes phase_table and needs an output")
+        _lib.call(
+            "xm_pipeline_fused_ramp", x2.data_ptr(), n_in, out.data_ptr(),
+            window.data_ptr() if window is not None else None, float(phase_ramp[0]), float(phase_ramp[1]), nb, n_in,
+            n_out, pad_left, flags, absmax2.data_ptr() if want_argmax else None,
+            argidx.data_ptr() if want_argmax else None, _dtype_code(x2), _stream(x2))
+        return FusedResult(out, absmax2 if want_argmax else None, argidx if want_argmax else None)
     _lib.call(
         "xm_pipeline_fused", x2.data_ptr(), n_in, out.data_ptr() if want_out else None,
         window.data_ptr() if window is not None else None,
@@ -350,21 +376,47 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
                        argidx if want_argmax else None)
 
 
-def row_l1(x2, window=None, pad_left: int = 0, out=None, n_used: int | None = None):
+def row_l1(x2, window=None, pad_left: int = 0, out=None, n_used: int | None = None, sub_step: int = 1, key=None):
     """Windowed L1 norm of every row of ``x2`` = [n_batch, n_in] (`xm_row_l1`): the cheap streaming guess for
     the row that holds the global maximum of the spectra.  `n_used` < n_in sums only the leading samples of
-    every row (a caller that knows the window's tail carries no weight skips reading it)."""
+    every row (a caller that knows the window's tail carries no weight skips reading it); `sub_step` > 1 sums
+    every sub_step-th 128-sample block of those (a ranking statistic on 1/sub_step of the bytes).  `key` (complex64:
+    `new_argmax_key`) receives the row with the largest norm in the same launch
+    (`argmax_key_take` decodes and clears it); the per-row norms are then not written unless `out` is given."""
     _require_device(x2)
     torch = _torch()
     if x2.dim() != 2 or not x2.is_contiguous():
         raise ValueError("row_l1 expects a contiguous [n_batch, n_in] tensor")
     nb, n_in = x2.shape
-    if out is None:
+    if out is None and key is None:
         out = torch.empty(nb, dtype=_real_dtype(x2), device=x2.device)
     n_sum = n_in if n_used is None else max(1, min(int(n_used), n_in))
     _lib.call("xm_row_l1", x2.data_ptr(), n_in, window.data_ptr() if window is not None else None, nb, n_sum,
-              int(pad_left), out.data_ptr(), _dtype_code(x2), _stream(x2))
+              int(pad_left), max(1, int(sub_step)), out.data_ptr() if out is not None else None,
+              key.data_ptr() if key is not None else None, _dtype_code(x2), _stream(x2))
     return out
+
+
+def new_argmax_key(device):
+    """A zeroed arg-max key buffer (XM_KEY_BYTES) for `row_l1(key=)` / `pipeline_fused(global_key=)`."""
+    return _torch().zeros(8192 // 8, dtype=_torch().int64, device=device)
+
+
+def argmax_key_take(key, n_per_row: int, gmax, gflat, x2=None, out_row=None):
+    """Decode a global arg-max key (`row_l1(key=)` / `pipeline_fused(global_key=)`) into `gmax` (float32, the value)
+    and `gflat` (int64, row * n_per_row) -- device-accessible one-element tensors -- and clear it; with `x2` also
+    gather the winning row as complex128 into `out_row` ([1, n_in])."""
+    torch = _torch()
+    if x2 is not None:
+        _require_device(x2)
+        if out_row is None:
+            out_row = torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device)
+    st = torch.cuda.current_stream(key.device).cuda_stream
+    _lib.call("xm_argmax_key_take", key.data_ptr(), int(n_per_row), gmax.data_ptr(), gflat.data_ptr(),
+              x2.data_ptr() if x2 is not None else None, x2.shape[1] if x2 is not None else 0,
+              x2.shape[1] if x2 is not None else 0, out_row.data_ptr() if x2 is not None else None,
+              _dtype_code(x2) if x2 is not None else _lib.XM_C64, st)
+    return out_row
 
 
 def argmax_reduce(absmax2, argidx, n: int):

@@ -93,7 +93,16 @@ class Selection:
     into pinned host memory, closed by an event.  `wait()` blocks on that event only, so kernels queued
     later on the same stream (another dataset's main pass) do not delay the host solver."""
 
-    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False):
+    @staticmethod
+    def new_slot(x2, plan: "PipelinePlan", real_dtype):
+        """Pinned host buffers (max, flat index, fp64 spectrum) + the device staging row of one selection in flight."""
+        import torch
+
+        return (torch.empty(1, dtype=real_dtype, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True),
+                torch.empty((1, plan.n_out), dtype=torch.complex128, pin_memory=True),
+                torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device))
+
+    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False, key=None, slot=None):
         import torch
 
         n = plan.n_out
@@ -106,17 +115,19 @@ class Selection:
         # complex128 spectrum kernel stores its 128 KiB row there -- no memcpy nodes on the stream.  The
         # buffers are reused across datasets (two sets: a streaming caller keeps at most two selections
         # in flight); allocating pinned memory per call costs more than the transfers.
-        rdt = absmax2.dtype
-        pool = plan.extra.setdefault("pinned", [])
-        turn = plan.extra["turn"] = (plan.extra.get("turn", -1) + 1) % 2
-        if len(pool) <= turn:
-            pool.append((torch.empty(1, dtype=rdt, pin_memory=True),
-                         torch.empty(1, dtype=torch.int64, pin_memory=True),
-                         torch.empty((1, n), dtype=torch.complex128, pin_memory=True),
-                         torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device)))
-        self.h_max, self.h_flat, self.h_slice, x1 = pool[turn]
-        dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
-        dev.gather_row_c128(x2, self.h_flat, n, out=x1)
+        rdt = absmax2.dtype if key is None else torch.float32
+        if slot is None:
+            pool = plan.extra.setdefault("pinned", [])
+            turn = plan.extra["turn"] = (plan.extra.get("turn", -1) + 1) % 2
+            if len(pool) <= turn:
+                pool.append(Selection.new_slot(x2, plan, rdt))
+            slot = pool[turn]
+        self.h_max, self.h_flat, self.h_slice, x1 = slot
+        if key is not None:  # the producer left the winner in a 64-bit key: decode + gather in one small launch
+            dev.argmax_key_take(key, n, self.h_max, self.h_flat, x2, out_row=x1)
+        else:
+            dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
+            dev.gather_row_c128(x2, self.h_flat, n, out=x1)
         dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
         self.event = torch.cuda.Event()
         self.event.record()
@@ -204,8 +215,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
         res = _selection_only(pre, plan, target_coord)
     if params is not None:
         res.p0, res.p1 = float(params[0]), float(params[1])
-    ph = upload_phase_table(plan, x2, res.p0, res.p1, res.pivot)
-    main = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, phase_table=ph, out=out)
+    main = main_pass(plan, x2, out, res.p0, res.p1, res.pivot)
     return main.out, res, plan
 
 
@@ -328,13 +338,11 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
         if broadcast is not None:
             res.p0, res.p1 = broadcast([res.p0, res.p1], owner_box[0])
         res.owner, res.mine = owner_box[0], mine
-        ev["t_solved"] = time.perf_counter()
-        ph = upload_phase_table(plan, inputs[i], res.p0, res.p1, res.pivot)
-        ev["t_table"] = time.perf_counter()
+        ev["t_solved"] = ev["t_table"] = time.perf_counter()
         if trace is not None:
             ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["main0"].record()
-        dev.pipeline_fused(inputs[i], n, plan.pad_left, window=plan.window, phase_table=ph, out=outputs[i])
+        main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot)
         if trace is not None:
             ev["main1"].record()
         if not overlap and i + 1 < n_sets:
@@ -347,8 +355,17 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
 
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
                             peak_width, p0_only, trace):
-    """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair)."""
+    """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair).
+
+    Software pipeline over the datasets (with `overlap`): while the main pass of dataset i is queued, the guess
+    kernels + selection stages of datasets up to i+3 are already on the stream and the (p0, p1) searches of
+    datasets i+1 and i+2 run on worker threads (each search is one native call that releases the GIL and brings its
+    own small team, `xm_solver_de`), so a search has two device periods to finish instead of racing one.  Every
+    dataset still gets all of its own work; the collective-like calls (`exchange`, `broadcast`) are made by this
+    thread in dataset order, identically on every rank."""
+    import os
     import time
+    from concurrent.futures import ThreadPoolExecutor
 
     import torch
 
@@ -356,19 +373,28 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     x0 = inputs[0]
     nb = x0.shape[0]
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
-    key = ("spec_bufs", nb, str(rd))
+    s_ahead = (2 if n_sets > 2 else 1) if overlap else 0   # searches running ahead of the main pass being queued
+    g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
+    ring = g_ahead + 2
+    use_keys = x0.dtype == torch.complex64 and dev.ramp_native(x0, plan.n_out, plan.pad_left)
+    key = ("spec_bufs", nb, str(rd), ring)
     bufs = plan.extra.get(key)
     if bufs is None:
         bufs = plan.extra[key] = dict(
-            norm=[torch.empty(nb, dtype=rd, device=x0.device) for _ in range(2)],
+            norm=[None if use_keys else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
             zero_idx=torch.zeros(nb, dtype=torch.int32, device=x0.device),
-            tmax=[torch.empty(nb, dtype=rd, device=x0.device) for _ in range(2)],
-            tidx=[torch.empty(nb, dtype=torch.int32, device=x0.device) for _ in range(2)],
-            vmax=[torch.empty(1, dtype=rd, pin_memory=True) for _ in range(2)],
-            vflat=[torch.empty(1, dtype=torch.int64, pin_memory=True) for _ in range(2)])
-    sel = [None, None]
+            tmax=[None if use_keys else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
+            tidx=[None if use_keys else torch.empty(nb, dtype=torch.int32, device=x0.device) for _ in range(ring)],
+            vmax=[torch.empty(1, dtype=rd, pin_memory=True) for _ in range(ring)],
+            vflat=[torch.empty(1, dtype=torch.int64, pin_memory=True) for _ in range(ring)],
+            # complex64: the guess kernel and the main kernel leave their winners in arg-max key buffers (no per-row
+            # arrays, no separate reductions); every key is cleared by the launch that decodes it
+            gkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
+            vkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
+            sel_slots=[Selection.new_slot(x0, plan, rd) for _ in range(ring)])
+    sel = [None] * ring
     events = [dict() for _ in range(n_sets)]
-    results = []
+    results = [None] * n_sets
     iw = aps.index_width_of(plan.freq, peak_width)
     # The guess needs a ranking, not the norm itself: samples whose window weight is negligible are not read.
     # n_used = the leading samples that carry all but 1e-3 of the window's total weight (rounded up to 256).
@@ -381,25 +407,58 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             n_used = int(np.searchsorted(np.cumsum(wabs), (1.0 - 1e-3) * total)) + 1
             n_used = min(plan.n_in, max(256, -(-n_used // 256) * 256))
         plan.extra["guess_n_used"] = n_used
+    # ... and of those, every `sub_step`-th 1-KiB block (whole cache lines spread over the window's support): the
+    # guess is verified by the main pass anyway, and a regular subset ranks rows like the full sum does
+    sub_step = plan.extra.get("guess_sub_step")
+    if sub_step is None:
+        sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "4")))
+    # searches in flight at once share the host: each gets an equal part of the team
+    n_workers = min(2, s_ahead) if s_ahead >= 2 else 0
+    team = max(1, aps.default_threads() // max(1, n_workers))
+    pool = None
+    if n_workers:
+        pool = plan.extra.get("search_pool")
+        if pool is None:
+            pool = plan.extra["search_pool"] = ThreadPoolExecutor(max_workers=2, thread_name_prefix="xm-search")
 
-    def guess(i):  # streaming L1 norms + the selection stage on the row with the largest one
-        b = i & 1
-        ev = events[i]
+    def guess(j):  # streaming L1 norms + the selection stage on the row with the largest one
+        b = j % ring
+        ev = events[j]
         if trace is not None:
             ev["pre0"], ev["pre1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["pre0"].record()
-        dev.row_l1(inputs[i], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used)
+        dev.row_l1(inputs[j], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used, sub_step=sub_step,
+                   key=bufs["gkey"][b])
         if trace is not None:
             ev["pre1"].record()
-        sel[b] = Selection(inputs[i], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True)
+        sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
+                           key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
 
     def search(sl, k, pivot):
-        p0, p1, opt = aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only)
-        return p0, p1, opt
+        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=team)
+
+    pending = {}  # dataset -> (partial result, future or None)
+
+    def start_search(j):
+        """Selection of dataset j -> (exchange) -> its search, inline or on a worker."""
+        ev = events[j]
+        ev["t_start"] = time.perf_counter()
+        amax, flat, sl = sel[j % ring].wait()  # (largest L1 norm, guessed row * n + arg-max of its fp64 spectrum, spectrum)
+        gflat, mine, owner = rank_offset_rows * n + flat, True, 0
+        if exchange is not None:  # the guess is global too: the rank with the largest norm owns it
+            mine, gflat, owner = exchange(amax, gflat)
+        ev["t_exchanged"] = time.perf_counter()
+        k = gflat % n
+        res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), amax)
+        res.owner, res.mine = owner, mine
+        fut = None
+        if mine:
+            fut = pool.submit(search, sl, int(k), res.pivot) if pool is not None else search(sl, int(k), res.pivot)
+        pending[j] = (res, fut)
 
     def verify(i):
         """True global arg-max row of dataset i (its main pass has been queued) against the guess; repair."""
-        b = i & 1
+        b = i % ring
         res, ev = results[i], events[i]
         ev["verify_event"].synchronize()
         tmax, trow = float(bufs["vmax"][b].item()) ** 0.5, int(bufs["vflat"][b].item()) // n
@@ -418,9 +477,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         if mine:
             row = g_row - rank_offset_rows
             x1 = inputs[i][row:row + 1].to(torch.complex128)
+            if plan.window64 is None:
+                plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x1.device, torch.float64)
             sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out[0].cpu().numpy()
             k = int(np.argmax(np.abs(sl)))
-            p0, p1, opt = search(sl, k, float(plan.freq[k]))
+            p0, p1, opt = aps.solve(sl, plan.freq, float(plan.freq[k]), k, iw, method=method, p0_only=p0_only)
             vals = [p0, p1, float(k), float(opt.nfev)]
         if broadcast is not None:
             vals = broadcast(vals, owner)
@@ -441,49 +502,80 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res.nfev = int(vals[3]) if mine else 0
         res.speculation = "repaired"
 
-    guess(0)
+    guessed = started = -1
     for i in range(n_sets):
-        b = i & 1
+        b = i % ring
         ev = events[i]
-        ev["t_start"] = time.perf_counter()
-        amax, flat, sl = sel[b].wait()  # (largest L1 norm, guessed row * n + arg-max of its fp64 spectrum, spectrum)
-        gflat, mine, owner = rank_offset_rows * n + flat, True, 0
-        if exchange is not None:  # the guess is global too: the rank with the largest norm owns it
-            mine, gflat, owner = exchange(amax, gflat)
-        ev["t_exchanged"] = time.perf_counter()
-        if overlap and i + 1 < n_sets:
-            guess(i + 1)
-        k = gflat % n
-        res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), amax)
-        if mine:
-            p0, p1, opt = search(sl, int(k), res.pivot)
+        while guessed < min(n_sets - 1, i + g_ahead):  # keep the guess kernels g_ahead datasets in front
+            guessed += 1
+            guess(guessed)
+        while started < min(n_sets - 1, i + s_ahead):  # ... and the searches s_ahead in front
+            started += 1
+            start_search(started)
+        res, fut = pending.pop(i)
+        if fut is not None:
+            p0, p1, opt = fut.result() if pool is not None else fut
             res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
             res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
         if broadcast is not None:
-            res.p0, res.p1 = broadcast([res.p0, res.p1], owner)
-        res.owner, res.mine = owner, mine
-        ev["t_solved"] = time.perf_counter()
-        ph = upload_phase_table(plan, inputs[i], res.p0, res.p1, res.pivot)
-        ev["t_table"] = time.perf_counter()
-        results.append(res)
+            res.p0, res.p1 = broadcast([res.p0, res.p1], res.owner)
+        ev["t_solved"] = ev["t_table"] = time.perf_counter()
+        results[i] = res
         if i > 0:  # dataset i-1's main pass is done (or about to be): settle its guess before outputs are reused
             verify(i - 1)
         if trace is not None:
             ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["main0"].record()
-        dev.pipeline_fused(inputs[i], n, plan.pad_left, window=plan.window, phase_table=ph, out=outputs[i],
-                           want_argmax=True, absmax2=bufs["tmax"][b], argidx=bufs["tidx"][b], argmax_value_only=True)
+        if use_keys:
+            main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot, global_key=bufs["vkey"][b])
+        else:
+            main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot, want_argmax=True, absmax2=bufs["tmax"][b],
+                      argidx=bufs["tidx"][b], argmax_value_only=True)
         if trace is not None:
             ev["main1"].record()
-        dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
+        if use_keys:
+            dev.argmax_key_take(bufs["vkey"][b], n, bufs["vmax"][b], bufs["vflat"][b])
+        else:
+            dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
         ev["verify_event"] = torch.cuda.Event()
         ev["verify_event"].record()
-        if not overlap and i + 1 < n_sets:
-            guess(i + 1)
         if trace is not None:
             trace.append(ev)
     verify(n_sets - 1)
     return results
+
+
+def phase_ramp_of(plan: PipelinePlan, p0: float, p1: float, pivot: float):
+    """phasing.py:56-69 on the plan's (uniform) frequency axis in closed form: phi[k] = phase0 + dphase * k.
+    Returns (phase0, dphase) in radians, or None when the axis is not uniform (a table is needed then)."""
+    lin = plan.extra.get("freq_linear")
+    if lin is None:
+        f = np.asarray(plan.freq, dtype=np.float64)
+        ok = f.size >= 2
+        if ok:
+            step = (f[-1] - f[0]) / (f.size - 1)
+            ok = step != 0 and bool(np.all(np.abs(f - (f[0] + step * np.arange(f.size))) <= 1e-12 * np.abs(f).max()))
+        lin = plan.extra["freq_linear"] = (float(f[0]), float(step), float(f.max() - f.min())) if ok else False
+    if lin is False:
+        return None
+    c0, step, rng = lin
+    if rng == 0:
+        return float(np.deg2rad(p0)), 0.0
+    return (float(np.deg2rad(p0) + np.deg2rad(p1) * (c0 - pivot) / rng), float(np.deg2rad(p1) * step / rng))
+
+
+def main_pass(plan: PipelinePlan, x2, out, p0: float, p1: float, pivot: float, **kw):
+    """The fused main pass with the autophase ramp: in closed form where the kernel applies it natively (no table
+    is built, nothing is uploaded), through a phase table otherwise."""
+    native = plan.extra.get(("ramp_native", x2.data_ptr() & 15, x2.shape[1], str(x2.dtype)))
+    if native is None:
+        native = plan.extra[("ramp_native", x2.data_ptr() & 15, x2.shape[1], str(x2.dtype))] = dev.ramp_native(
+            x2, plan.n_out, plan.pad_left)
+    ramp = phase_ramp_of(plan, p0, p1, pivot) if native else None
+    if ramp is not None:
+        return dev.pipeline_fused(x2, plan.n_out, plan.pad_left, window=plan.window, phase_ramp=ramp, out=out, **kw)
+    ph = upload_phase_table(plan, x2, p0, p1, pivot)
+    return dev.pipeline_fused(x2, plan.n_out, plan.pad_left, window=plan.window, phase_table=ph, out=out, **kw)
 
 
 def upload_phase_table(plan: PipelinePlan, like, p0: float, p1: float, pivot: float):

@@ -67,13 +67,16 @@ class ShmExchange:
     cannot start before it).  Created collectively (`ShmExchange.create(dist, group)`): rank 0 makes a file
     under /dev/shm, every rank maps it, rank 0 unlinks it at once -- nothing is left behind, even on a crash.
 
-    Layout (int64 words, float64 stored as bit patterns): two banks (dataset parity) of
-    `world` gather slots [seq, max_abs, flat, -] and one broadcast slot [seq, n, v0, v1, ...].
-    A rank can run at most one exchange ahead of the slowest one (it needs everyone's entry to finish the
-    next gather), so two banks are enough.  x86 stores are observed in program order: payload first, then
-    the sequence number that publishes it."""
+    Layout (int64 words, float64 stored as bit patterns): BANKS banks of `world` gather slots
+    [seq, max_abs, flat, -] and one broadcast slot [seq, n, v0, v1, ...].  Gathers and broadcasts carry their OWN
+    sequence numbers (a streaming caller runs the gathers of later datasets before the broadcast of an earlier
+    one) and pick their bank by that number.  A rank can run at most one gather ahead of the slowest one (it needs
+    everyone's entry to finish the next gather), and callers put at least one gather between two broadcasts, so
+    two banks would do; four leave slack.  x86 stores are observed in program order: payload first, then the
+    sequence number that publishes it."""
 
-    SLOT = 8  # int64 words per slot = one 64-byte cache line
+    SLOT = 8   # int64 words per slot = one 64-byte cache line
+    BANKS = 4
 
     def __init__(self, buf, rank: int, world: int, timeout_s: float = 120.0):
         import numpy as np
@@ -88,13 +91,14 @@ class ShmExchange:
         except Exception:
             pass
         words = np.frombuffer(buf, dtype=np.int64)
-        self._i = words[: 2 * (world + 1) * self.SLOT].reshape(2, world + 1, self.SLOT)
+        self._i = words[: self.BANKS * (world + 1) * self.SLOT].reshape(self.BANKS, world + 1, self.SLOT)
         self._f = self._i.view(np.float64)
-        self._seq = 0
+        self._seq = 0   # gathers done
+        self._bseq = 0  # broadcasts done
 
     @staticmethod
     def nbytes(world: int) -> int:
-        return max(4096, 2 * (world + 1) * ShmExchange.SLOT * 8)
+        return max(4096, ShmExchange.BANKS * (world + 1) * ShmExchange.SLOT * 8)
 
     @classmethod
     def create(cls, dist, group=None, timeout_s: float = 120.0):
@@ -156,7 +160,7 @@ class ShmExchange:
     def exchange_argmax(self, max_abs: float, global_flat: int):
         """Every rank contributes (max |X|, global flat index); returns pick_winner() of all of them."""
         self._seq += 1
-        s, bank = self._seq, self._seq & 1
+        s, bank = self._seq, self._seq % self.BANKS
         slots_i, slots_f = self._i[bank], self._f[bank]
         slots_f[self.rank, 1] = float(max_abs)
         slots_i[self.rank, 2] = int(global_flat)
@@ -166,8 +170,9 @@ class ShmExchange:
         return pick_winner([(float(slots_f[r, 1]), int(slots_i[r, 2])) for r in range(self.world)])
 
     def broadcast_params(self, values, owner: int):
-        """`owner` publishes a short list of float64 values for the dataset of the last exchange_argmax()."""
-        s, bank = self._seq, self._seq & 1
+        """`owner` publishes a short list of float64 values; every rank makes the same sequence of calls."""
+        self._bseq += 1
+        s, bank = self._bseq, self._bseq % self.BANKS
         bi, bf = self._i[bank, self.world], self._f[bank, self.world]
         if self.rank == owner:
             vals = [float(v) for v in values]
