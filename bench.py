@@ -18,8 +18,14 @@ pre-pass) kernel of step i+1 is queued while the host solves step i (`--no-overl
 Workload at N=1: BASELINE.json configs[2] (65,536 voxels x 4096-pt complex64 FIDs zero-filled to 8192).  With
 --gpus N every rank owns its own 65,536-voxel shard of ONE dataset (weak scaling).
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment): this process starts N rank processes itself, one
+per GPU, BEFORE anything touches a GPU (it never re-executes a process that has), relays rank 0's JSON line and exits
+with the worst child status; it refuses to run when fewer than N devices are visible.
+
 Prints ONE JSON line on rank 0's stdout (see the driver contract; library chatter goes to stderr); `roofline`
-prices the dominant (main) kernel by HIP events on its stream, `cpu_baseline` times the CPU oracle.
+prices the dominant (main) kernel by HIP events on its stream, `cpu_baseline` times the CPU oracle.  The line
+carries its own footnotes, measured after the timed region (they never enter `value`): the classic schedule's
+rate, one dataset end to end without cross-dataset overlap, the cost of a wrong guess, a complex128 sub-record.
 """
 import argparse
 import json
@@ -42,6 +48,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # stores; the per-wave atomic maxima count as partial lines).  The classic schedule's mode-3 kernel measured
 # 1,049,256 KB / 4,194,304 KB.
 PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049751.7 + 4205141.4) * 1024)
+PMC_SOURCE = "profiles/r01/pmc_main_kernel.txt"
 
 
 def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, dtype):
@@ -67,6 +74,35 @@ def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, 
     return x, t
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as child processes (the environment torchrun
+    would give them), relay rank 0's stdout.  Nothing here initialises a GPU."""
+    import socket
+    import subprocess
+
+    import torch  # importing is safe; device_count() does not create a context on this stack
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (n_dev < args.gpus and not args.share_gpu):
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {n_dev} device(s) visible\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XM_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +126,15 @@ def main():
                          "winning row from the FIDs' windowed L1 norms (pipeline.run_stream(speculate=...))")
     ap.add_argument("--exchange", choices=["shm", "gloo"], default="shm",
                     help="N > 1: the O(1) host exchange goes through a shared-memory page (one node) or gloo")
+    ap.add_argument("--prime-ms", type=float, default=200.0,
+                    help="untimed steps run before the warm-up until this much wall time has passed (clocks, caches, "
+                         "page tables and the software pipeline reach their steady state however short --warmup is)")
+    ap.add_argument("--no-footnotes", action="store_true",
+                    help="skip the extra measurements after the timed region (classic schedule, single dataset, forced "
+                         "miss, complex128)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     # Libraries chat on stdout (RCCL prints a five-line banner at communicator creation, gloo a line per rank): the
     # contract is ONE JSON line there.  File descriptor 1 is pointed at stderr for the whole run; the result line goes
@@ -108,17 +152,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if args.share_gpu:
         local_rank = 0
-    local_rank %= max(1, torch.cuda.device_count())  # a launcher may expose one device per rank
+    n_dev = torch.cuda.device_count()
+    if not args.share_gpu and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev > 1:
+        raise SystemExit(f"{world} ranks on this node but only {n_dev} devices visible")
+    local_rank %= max(1, n_dev)  # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     host_group = None
     shm = None
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
 
@@ -131,6 +179,10 @@ def main():
         # the O(1) arg-max exchange and (p0, p1) broadcast are host-side metadata: a gloo group keeps
         # them from queueing behind the kernels of other datasets already on the GPU stream
         host_group = dist.new_group(backend="gloo")
+        if args.dist_backend == "nccl":  # how many ranks RCCL really spans (an all_reduce of ones)
+            ones = torch.ones(1, dtype=torch.int32, device=device)
+            dist.all_reduce(ones)
+            rccl_ranks = int(ones.item())
         # on one node the same exchange goes through a shared-memory page (microseconds instead of two
         # loopback collectives per dataset); every rank must agree on the choice, so failures are gathered
         if args.exchange == "shm":
@@ -211,15 +263,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup:
-        run_steps(args.warmup, False)
     # A full (generation-2) garbage collection over the interpreter's ~10^5 long-lived objects (torch, numpy) takes
-    # 10+ ms -- five steps.  Collect now and move everything alive into the permanent generation: the cyclic
-    # garbage the timed loop creates is then collected in microseconds.
+    # 10+ ms -- several steps.  Collect now and move everything alive into the permanent generation: the cyclic
+    # garbage the timed loop creates is then collected in microseconds.  Done BEFORE the priming so that the device
+    # does not sit idle (and clock down) between the last untimed step and the first timed one.
     import gc
 
+    run_steps(2, False)  # first use: plans, tables, pinned buffers, worker threads
     gc.collect()
     gc.freeze()
+    if args.prime_ms > 0:  # untimed: until the wall clock says the device has been busy for a while
+        t_prime = time.perf_counter()
+        while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+            run_steps(8, False)
+    if args.warmup:
+        run_steps(args.warmup, False)
     barrier()
     t_start = time.perf_counter()
     run_steps(args.steps, True)
@@ -237,6 +295,15 @@ def main():
     alg_bytes = (bytes_per * nt + bytes_per * N) * nv  # read each FID once + write each spectrum once
     achieved = alg_bytes / (main_ms * 1e-3) / 1e9
     stream_ms = main_ms + pre_ms
+    hot = (nt, N) == (4096, 8192)
+    if args.dtype == "c64":
+        kernel = ("k_zf2p<FftPlan<4096,256,16,16,16>, " + ("13" if speculate else "9") + ", 11>" if hot
+                  else "xm_pipeline_fused_ramp main pass")
+    else:
+        kernel = ("k_zf2<double, FftPlan<4096,512,8,8,8,8>, " + ("23" if speculate else "3") + ">" if hot
+                  else "xm_pipeline_fused main pass")
+    kernel += " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
+    static_traffic = (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None)
 
     result = {
         "metric": "spectra/sec (zero_fill->apodize->FFT->autophase), n_time=4096; HBM-roofline %",
@@ -257,24 +324,21 @@ def main():
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": ((f"k_zf2<float, FftPlan<4096,256,16,16,16>, {7 if speculate else 3}>" if args.dtype == "c64" else
-                                        f"k_zf2<double, FftPlan<4096,512,8,8,8,8>, {7 if speculate else 3}>")
-                                       if (nt, N) == (4096, 8192) else "xm_pipeline_fused main pass")
-                                      + " (zero-fill+window+FFT+fftshift+phase" + ("+per-row maxima)" if speculate else ")"),
+            "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype, speculate) == (65536, 4096, 8192, "c64", True)
-                        else (int((2 * 1049256.0 + 4194304.0) * 1024)
-                              if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None)),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01/pmc_main_kernel.txt",
+            "traffic": static_traffic, "traffic_static": True,
+            "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of "
+                              "this kernel on this workload, " + PMC_SOURCE,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
         },
         "breakdown_ms": {
             ("guess_kernel_row_l1" if speculate else "prepass_kernel"): pre_ms, "main_kernel": main_ms,
-            "argmax_reduce_and_exchange": float(np.mean(times["exchange_ms"])),
-            "slice_de_solve_broadcast": float(np.mean(times["solve_ms"])),
+            "selection_wait_and_exchange": float(np.mean(times["exchange_ms"])),
+            # speculative schedule: searches run two datasets ahead on worker threads -- this is the LATENCY from a
+            # dataset's exchange to the moment its (p0, p1) is consumed, not host time on the critical path
+            ("search_latency_exchange_to_use" if speculate else "slice_de_solve_broadcast"): float(np.mean(times["solve_ms"])),
             "solver_generations": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
             "solver_polish": float(np.mean(times["polish_ms"])) if times["polish_ms"] else None,
-            "phase_table_and_upload": float(np.mean(times["table_ms"])),
             "device_period_min_median_max": ([float(np.min(times["period_ms"])), float(np.median(times["period_ms"])),
                                               float(np.max(times["period_ms"]))] if times["period_ms"] else None),
             "device_period_p90_p99": ([float(np.percentile(times["period_ms"], 90)),
@@ -282,15 +346,21 @@ def main():
             "streaming_spectra_per_s_per_gpu": nv / (stream_ms * 1e-3),
             "streaming_roofline_frac": alg_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         },
+        "end_to_end_roofline_frac": value / world * (bytes_per * nt + bytes_per * N) / 1e9 / HBM_PEAK_GBPS,
         "autophase": {k: last.get(k) for k in ("p0", "p1", "pivot", "flat", "owner", "nfev")},
-        "schedule": (("guess pass (windowed L1 norms) of step i+1 overlaps the host solve of step i; the main pass "
-                      "returns the true per-row maxima and the guess is verified (repaired if wrong) before the next "
-                      "main pass" if speculate else
+        "schedule": (("guess kernels run 3 and (p0, p1) searches 2 datasets ahead of the main pass being queued (independent "
+                      "datasets); the main pass returns the true global arg-max and every guess is verified (repaired if "
+                      "wrong) before the next main pass" if speculate else
                       "pre-pass of step i+1 overlaps the host solve of step i (independent datasets)") if overlap
                      else "strictly serial steps"),
         "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0)}
                         if speculate else {"enabled": False}),
+        "prime_ms": args.prime_ms,
     }
+    if rccl_ranks is not None:
+        result["rccl_ranks"] = rccl_ranks
+    if not args.no_footnotes and world == 1:
+        result.update(footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms, alg_bytes))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, t, N, args.lb, args.cpu_seconds, nv)
@@ -301,6 +371,80 @@ def main():
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms, alg_bytes):
+    """What the headline does not say by itself, measured after the timed region on the same buffers:
+      value_classic_schedule   the same workload with the arg-max pre-pass instead of the verified guess
+      single_dataset_ms        ONE dataset end to end (guess -> search -> main -> verify), nothing to overlap with
+      speculation.miss_*       the synthetic voxels share one spectral shape, so the guess never misses in the timed
+                               region; here one row is rebuilt so that it has the largest L1 norm but not the tallest
+                               peak and every step has to be repaired (second search + in-place phase rotation)
+      c128                     complex128 storage (the reference's arithmetic, fid.py:136-139), half the voxels"""
+    import time
+
+    nv = x.shape[0]
+    notes = {}
+
+    def rate(inputs, outputs, pl, n, spec):
+        pipeline.run_stream(inputs[:4], outputs[:4], pl, speculate=spec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipeline.run_stream(inputs[:n], outputs[:n], pl, speculate=spec)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, res
+
+    k = max(8, min(args.steps, 40))
+    ms, _ = rate([x] * k, [out] * k, plan, k, False)
+    notes["value_classic_schedule"] = nv / (ms * 1e-3)
+    notes["classic_schedule_ms_per_step"] = ms
+    singles = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipeline.run_stream([x], [out], plan, speculate=speculate)
+        torch.cuda.synchronize()
+        singles.append((time.perf_counter() - t0) * 1e3)
+    notes["single_dataset_ms"] = float(np.median(singles[2:]))
+    notes["single_dataset_spectra_per_s"] = nv / (notes["single_dataset_ms"] * 1e-3)
+    if speculate:
+        # forced miss: row 7 = thirty lines of height 1.2 (largest windowed L1 norm; the brightest voxel peaks at 2.0)
+        xm = x.clone()
+        tt = torch.from_numpy(np.asarray(t)).to(x.device)
+        row = torch.zeros(x.shape[1], dtype=torch.complex128, device=x.device)
+        for j in range(30):  # >= 76 Hz apart (no two lines add up), spacing jittered so that the sum has no period
+            f0 = -2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)
+            row += torch.exp(-20.0 * tt) * torch.exp(2j * np.pi * f0 * tt)
+        xm[7] = (1.2 * row).to(x.dtype)
+        ms_miss, res = rate([xm] * 12, [out] * 12, plan, 12, True)
+        ms_hit, _ = rate([x] * 12, [out] * 12, plan, 12, True)
+        n_rep = sum(r.speculation == "repaired" for r in res)
+        notes["speculation_miss"] = {"forced_miss_steps": 12, "repaired": n_rep, "ms_per_step_all_missed": ms_miss,
+                                     "ms_per_step_all_hit_same_length": ms_hit,
+                                     "miss_penalty_ms": (ms_miss - ms_hit) if n_rep == 12 else None}
+        del xm
+    if args.dtype == "c64":
+        try:
+            nv2 = nv // 2
+            x2 = x[:nv2].to(torch.complex128)
+            out2 = torch.empty((nv2, N), dtype=torch.complex128, device=x.device)
+            plan2 = pipeline.make_plan(x2, t, N, args.lb)
+            trace = []
+            pipeline.run_stream([x2] * 4, [out2] * 4, plan2, speculate=speculate)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipeline.run_stream([x2] * 16, [out2] * 16, plan2, speculate=speculate, trace=trace)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) / 16 * 1e3
+            main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
+            bytes2 = 16 * (x2.shape[1] + N) * nv2
+            notes["c128"] = {"voxels": nv2, "value": nv2 / (ms2 * 1e-3), "ms_per_step": ms2, "main_kernel_ms": main2,
+                             "main_kernel_frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "end_to_end_roofline_frac": nv2 / (ms2 * 1e-3) * 16 * (x2.shape[1] + N) / 1e9 / HBM_PEAK_GBPS}
+            del x2, out2
+        except Exception as e:  # an out-of-memory box must not cost the headline
+            notes["c128"] = {"error": repr(e)[:200]}
+    return notes
 
 
 def cpu_baseline(x, t, N, lb, budget_s, nv_full):

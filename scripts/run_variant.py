@@ -1,22 +1,32 @@
-"""Run one fused-kernel variant a few times (for rocprofv3 counter passes).
-VARIANT in {write, pre, main, all, guess};  NV voxels (default 65536).
-  all   = the main pass of the speculative schedule (write + phase + per-row maxima, value only)
-  guess = the windowed L1 norms (xm_row_l1) that replace the pre-pass in that schedule"""
+"""Run one fused-kernel variant a few times (for rocprofv3 counter passes) on the C3 shape (NV x 4096 -> 8192, c64).
+VARIANT:
+  all   = main pass of the speculative schedule: k_zf2p mode 13 (write + phase ramp + global arg-max key)
+  main  = main pass of the classic schedule: k_zf2p mode 9 (write + phase ramp)
+  table = write + phase TABLE (k_zf2p mode 3; the first-generation kernel with XM_ZF2_GEN1=1)
+  write = write only;  pre = arg-max pre-pass of the classic schedule
+  guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmris_amd import device as dev
 nv, nt, N = int(os.environ.get("NV", 65536)), int(os.environ.get("NT", 4096)), int(os.environ.get("NOUT", 8192))
-var = os.environ.get("VARIANT", "main")
+var = os.environ.get("VARIANT", "all")
 x = torch.view_as_complex(torch.randn(nv, nt, 2, device="cuda"))
 w = torch.rand(N, device="cuda")
 ph = torch.view_as_complex(torch.randn(N, 2, device="cuda"))
 out = torch.empty(nv, N, dtype=torch.complex64, device="cuda")
 am = torch.empty(nv, device="cuda"); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
+key = dev.new_argmax_key("cuda")
+gmax = torch.empty(1, device="cuda"); gflat = torch.empty(1, dtype=torch.int64, device="cuda")
+ramp = (0.7, 0.0085)
 kw = {"guess": {}, "write": dict(want_out=True), "pre": dict(want_out=False, want_argmax=True, argmax_value_only=True),
-      "main": dict(want_out=True, phase_table=ph), "all": dict(want_out=True, phase_table=ph, want_argmax=True, argmax_value_only=True)}[var]
+      "table": dict(want_out=True, phase_table=ph), "main": dict(want_out=True, phase_ramp=ramp),
+      "all": dict(want_out=True, phase_ramp=ramp, global_key=key)}[var]
 for _ in range(int(os.environ.get("REPS", 3))):
     if var == "guess":
-        dev.row_l1(x, w, 0, out=am)
+        dev.row_l1(x, w, 0, n_used=2304, sub_step=4, key=key)
+        dev.argmax_key_take(key, N, gmax, gflat)
     else:
-        dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=am, argidx=ai, **kw)
+        dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=None if var == "all" else am, argidx=None if var == "all" else ai, **kw)
+        if var == "all":
+            dev.argmax_key_take(key, N, gmax, gflat)
 torch.cuda.synchronize()

@@ -208,6 +208,66 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
     assert got[3].flat_index // target == 50
 
 
+def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods):
+    """The guess kernel sums every 4th 1-KiB block of the leading samples only.  Row 9 of dataset 1 carries ALL its
+    signal in blocks the guess skips (samples 128...511: a delayed burst), and the tallest peak of the dataset: the
+    full L1 norm would find it, the subset cannot.  The verification must catch it and the repaired result must equal
+    the classic schedule's; dataset 0 (ordinary decaying rows) is a hit."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 48, 1024, 2048
+    t = np.arange(nt) * 2e-4
+    sets = []
+    for k in range(2):
+        x, _ = _three_peak(nv, nt, 2e-4, seed=500 + k)
+        x[(5 * k + 2) % nv] *= 2.0
+        if k == 1:
+            burst = np.zeros(nt, dtype=np.complex128)
+            burst[128:512] = 12.0 * np.exp(2j * np.pi * 650.0 * t[128:512])  # 384 samples of one frequency
+            x[9] = burst
+        sets.append(dev.to_device(x.astype(np.complex64)))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=torch.complex64, device="cuda") for _ in sets]
+    refs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, refs, plan)
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert ref[1].flat_index // target == 9, "the burst row must hold the global maximum"
+    assert [r.speculation for r in got] == ["hit", "repaired"]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert (a.flat_index, a.target_idx, a.pivot, a.p0, a.p1) == (b.flat_index, b.target_idx, b.pivot, b.p0, b.p1), k
+        scale = float(refs[k].abs().max())
+        assert float((outs[k] - refs[k]).abs().max()) < 1e-6 * scale, k
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two rank processes itself (sharing this GPU here, gloo
+    instead of RCCL) and report n_gpus == 2; with one visible device and no --share-gpu it must refuse (exit != 0)
+    instead of quietly benchmarking one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "3",
+           "--warmup", "1", "--voxels", "2048", "--no-cpu-baseline", "--prime-ms", "0"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["voxels_per_gpu"] == 2048
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "device(s) visible" in r.stderr
+
+
 def test_speculative_schedule_two_ranks_with_cross_rank_repair():
     """Two ranks (sharing this GPU, gloo + the shared-memory exchange) run run_stream(speculate=True) on shards of
     datasets whose L1-norm winner lives on rank 0 while the true maximum lives on rank 1: the verification

@@ -1148,13 +1148,42 @@ __global__ __launch_bounds__(256) void k_row_l1(const Cx<T>* __restrict__ in, lo
   // (128 complex64 samples), every sub_step-th block
   auto word_of = [&](int v) { return sub_step <= 1 ? v : ((v >> 6) * sub_step << 6) + (v & 63); };
   unsigned long long best = 0;  // gkey: best (norm, row) of this wave's rows, merged once at the end
+  const int nvec = n_in / PER;
+  const int nblk = (nvec + 63) >> 6;
+  const int nsub = sub_step <= 1 ? nvec : (((nblk + sub_step - 1) / sub_step) << 6);  // words of the subset (upper bound)
+  // the subset usually fits ONE round of UN words per lane: the lane's window weights are then the same for every
+  // row and live in registers (re-reading them per row cost as many L2 bytes as the samples themselves)
+  const bool one_round = wide && nsub <= XM_WAVE * UN;
+  T wreg[UN][PER];
+  if (one_round) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int v = lane + XM_WAVE * u, j = word_of(v) * PER;
+#pragma unroll
+      for (int e = 0; e < PER; ++e)
+        wreg[u][e] = (v < nsub && j + e < n_in) ? (window ? fabs(window[j + e + pad_left]) : T(1)) : T(0);
+    }
+  }
   for (long long b = wave; b < n_batch; b += nwaves) {
     const Cx<T>* __restrict__ row = in + b * in_stride;
     T acc = T(0);
-    if (wide) {
-      const int nvec = n_in / PER;
-      const int nblk = (nvec + 63) >> 6;
-      const int nsub = sub_step <= 1 ? nvec : (((nblk + sub_step - 1) / sub_step) << 6);  // words of the subset (upper bound)
+    if (one_round) {
+      Cx<T> x[UN][PER];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int v = lane + XM_WAVE * u;
+        const int j = min(word_of(v), nvec - 1);  // clamped: words beyond the subset carry weight 0
+        const xm_u4 raw = *reinterpret_cast<const xm_u4*>(row + (long long)j * PER);
+        __builtin_memcpy(&x[u][0], &raw, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {  // weight 0 = not part of the sum (a clamped duplicate): never 0 * inf
+          const T m = sqrt(x[u][e].re * x[u][e].re + x[u][e].im * x[u][e].im);
+          acc += wreg[u][e] != T(0) ? m * wreg[u][e] : T(0);
+        }
+    } else if (wide) {
       for (int j0 = lane; j0 < nsub; j0 += XM_WAVE * UN) {
         Cx<T> x[UN][PER];
 #pragma unroll

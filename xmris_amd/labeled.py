@@ -170,6 +170,12 @@ class LabeledArray:
         for k, c in da.coords.items():
             if c.ndim == 1:
                 coords[str(k)] = Coordinate(c.dims[0], np.asarray(c.values), dict(c.attrs))
+            elif c.ndim > 1:
+                # xarray carries multi-dimensional coordinates through every operation; this container cannot, and
+                # dropping one silently would hand back a different object than the reference does
+                raise NotImplementedError(f"coordinate {k!r} spans {c.ndim} dimensions {tuple(c.dims)}: xmris_amd carries "
+                                          f"one-dimensional coordinates only (drop or reset it before the call)")
+            # 0-d (scalar) coordinates carry no axis information for this path and are not kept
         return cls(np.asarray(da.values), da.dims, coords, dict(da.attrs), da.name)
 
     def to_xarray(self):

@@ -241,9 +241,8 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
     sum|z|/sqrt(N) bounds every |X[k]| of a row and equals the peak of a single decaying resonance).  (p0, p1)
     is searched on the guessed row's spectrum, the main pass applies it AND returns the true per-row maxima, and
     the true global arg-max row is compared with the guess before the next main pass is queued.  A wrong guess
-    is repaired exactly: the true row's spectrum is fetched, (p0, p1) searched again and the dataset's output
-    multiplied in place by e^{i (phi_true - phi_guess)}; results equal the non-speculative schedule's up to one
-    rounding of the storage precision.  How often the guess is right depends on the data (rows of similar
+    is repaired exactly: the true row's spectrum is fetched, (p0, p1) searched again and the dataset's main pass
+    run again with them; the result equals the non-speculative schedule's.  How often the guess is right depends on the data (rows of similar
     spectral shape: always); correctness never does.
 
     `trace`, if given, receives one dict per dataset: host timestamps (`t_start`, `t_exchanged`, `t_solved`,
@@ -414,7 +413,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "4")))
     # searches in flight at once share the host: each gets an equal part of the team
     n_workers = min(2, s_ahead) if s_ahead >= 2 else 0
-    team = max(1, aps.default_threads() // max(1, n_workers))
+    team = max(1, aps.default_threads() // max(1, n_workers))  # per search in flight
     pool = None
     if n_workers:
         pool = plan.extra.get("search_pool")
@@ -434,8 +433,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
                            key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
 
-    def search(sl, k, pivot):
-        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=team)
+    full_team = aps.default_threads()
+
+    def search(sl, k, pivot, threads):
+        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads)
 
     pending = {}  # dataset -> (partial result, future or None)
 
@@ -453,7 +454,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res.owner, res.mine = owner, mine
         fut = None
         if mine:
-            fut = pool.submit(search, sl, int(k), res.pivot) if pool is not None else search(sl, int(k), res.pivot)
+            # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
+            # at a time and have two device periods each
+            th = full_team if j == 0 else team
+            fut = pool.submit(search, sl, int(k), res.pivot, th) if pool is not None else search(sl, int(k), res.pivot, th)
         pending[j] = (res, fut)
 
     def verify(i):
@@ -487,16 +491,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             vals = broadcast(vals, owner)
         p0, p1, k = float(vals[0]), float(vals[1]), int(vals[2])
         pivot = float(plan.freq[k])
-        ratio = np.exp(1j * (aps.phase_angles(plan.freq, p0, p1, pivot)
-                             - aps.phase_angles(plan.freq, res.p0, res.p1, res.pivot)))
-        if np.ndim(ratio) == 0:
-            ratio = np.full(n, ratio)
-        rt = torch.from_numpy(np.ascontiguousarray(ratio)).to(outputs[i].device, outputs[i].dtype)
-        from . import _lib
-
-        o = outputs[i]
-        _lib.call("xm_phase_apply", o.data_ptr(), o.data_ptr(), rt.data_ptr(), o.shape[0], n, dev._dtype_code(o),
-                  dev._stream(o))
+        # the dataset's FIDs are still there: run its main pass again with the right parameters (one read + one
+        # write of the dataset, and the result is the classic schedule's to the bit; rotating the wrong output in
+        # place by the phase ratio reads AND writes the spectra and adds two roundings)
+        main_pass(plan, inputs[i], outputs[i], p0, p1, pivot)
         res.p0, res.p1, res.pivot, res.target_idx = p0, p1, pivot, k
         res.flat_index, res.max_abs, res.owner, res.mine = g_row * n + k, tmax, owner, mine
         res.nfev = int(vals[3]) if mine else 0

@@ -19,6 +19,25 @@ def device_data(da: LabeledArray):
     return dev.to_device(da.data), was_real
 
 
+def promote_for_float64_operand(x):
+    """numpy's promotion when an array meets a float64 / complex128 operand (the reference multiplies by
+    ``np.exp(-pi*lb*t)`` -- float64, fid.py:136-139 -- or by ``np.exp(1j*phi)`` -- complex128, phasing.py:73,
+    vendor/bruker.py:83): single precision becomes double, so from the first such step on the reference's chain is
+    complex128 whatever the FID's storage was.  The staged calls follow it (their results feed `autophase`, whose
+    search is sensitive to the last bits of its input); the fused `spectral_pipeline` keeps the storage precision and
+    recomputes the one arg-max spectrum in complex128 instead.  ``XMRIS_AMD_KEEP_COMPLEX64=1`` switches the
+    promotion off."""
+    import os
+
+    if os.environ.get("XMRIS_AMD_KEEP_COMPLEX64"):
+        return x
+    if hasattr(x, "detach"):
+        import torch
+
+        return x.to(torch.complex128) if x.dtype == torch.complex64 else x
+    return x.astype(np.complex128) if x.dtype == np.complex64 else x
+
+
 def maybe_real(x, was_real: bool):
     """Ops that keep a real array real in the reference (pad, roll, real window) return the real part."""
     if not was_real:

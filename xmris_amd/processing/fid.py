@@ -14,7 +14,7 @@ from .. import device as dev
 from ..config import ATTRS, COORDS, DIMS
 from ..dims import _check_dims, term_attrs
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
-                      maybe_real)
+                      maybe_real, promote_for_float64_operand)
 from .fourier import fft, fftshift, ifft, ifftshift
 
 
@@ -46,6 +46,7 @@ def to_fid(da, dim: str = DIMS.frequency, out_dim: str = DIMS.time):
 
 def _apodize(src: LabeledArray, dim: str, weight: np.ndarray) -> LabeledArray:
     x, was_real = device_data(src)
+    x = promote_for_float64_operand(x)  # complex64 * float64 window -> complex128 (fid.py:136-139)
     y = maybe_real(dev.apodize(x, src.get_axis_num(dim), weight), was_real)
     out = src.copy(data=y)
     out.name = binary_op_name(src, dim)

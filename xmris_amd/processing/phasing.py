@@ -18,7 +18,7 @@ from .. import device as dev
 from ..config import ATTRS, DIMS
 from ..dims import _check_dims
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
-                      to_host)
+                      promote_for_float64_operand, to_host)
 
 
 def _global_argmax(src: LabeledArray, x):
@@ -30,7 +30,7 @@ def _global_argmax(src: LabeledArray, x):
 def _phase_labeled(src: LabeledArray, x, dim, p0, p1, pivot) -> LabeledArray:
     coords = src.coords[dim].values
     table = aps.phase_table(coords, p0, p1, pivot)  # fp64 on the host (phasing.py:56-73)
-    y = dev.phase_apply(x, src.get_axis_num(dim), table)
+    y = dev.phase_apply(promote_for_float64_operand(x), src.get_axis_num(dim), table)  # * complex128 (phasing.py:73)
     out = src.copy(data=y)
     out.name = binary_op_name(src, dim)
     out.attrs = _copy.copy(src.attrs)  # phasing.py:76
