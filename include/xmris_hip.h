@@ -53,8 +53,15 @@ typedef enum {
 #define XM_AMAX_GLOBAL_KEY 32u /* xm_pipeline_fused(_ramp), geometries of xm_pipeline_ramp_native only: `absmax2` points to
                                   an arg-max KEY BUFFER (XM_KEY_BYTES bytes, zero at launch) that receives the global
                                   arg-max of the launch as partial keys, max |X|^2 float bits << 32 | (0xffffffff - row);
-                                  no per-row outputs, `argidx` unused.  xm_argmax_key_take merges, decodes and clears it. */
+                                  no per-row outputs.  `argidx` == NULL: the key stays for xm_argmax_key_take (merges,
+                                  decodes, clears).  `argidx` != NULL: it points to a result record `xm_argmax_result`, device-accessible --
+                                  e.g. pinned host memory -- that the kernel's last workgroup fills itself, clearing the key. */
 #define XM_KEY_BYTES 8192     /* 64 partial keys on cache lines of their own */
+typedef struct {
+  float max2;   /* max |X|^2 of the launch                      */
+  float pad_;
+  int64_t flat; /* winning row * n_out (index along the axis: 0) */
+} xm_argmax_result;
 
 int xm_version(void); /* 10000*major + 100*minor + patch */
 const char* xm_last_error_string(void);

@@ -412,3 +412,106 @@ def test_row_l1_matches_numpy(dev, nb, n_in, pad_left, n_used, dtype):
     keep = ((np.arange(m) // per_block) % 3 == 0)
     ref_s = (np.abs(x.astype(np.complex128))[:, :m] * np.abs(w[pad_left:pad_left + m]) * keep).sum(axis=1)
     np.testing.assert_allclose(dev.row_l1(xd, wd, pad_left, n_used=n_used, sub_step=3).cpu().numpy(), ref_s, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_argmax_returns_the_first_nan_like_numpy(dev, dtype):
+    """phasing.py:229 `np.argmax(np.abs(values))` returns the FIRST NaN when there is one (NaN compares as the maximum
+    in numpy's arg-max).  Staged arg-max on an array with NaNs, and the fused kernels on FIDs with a NaN sample (the
+    whole spectrum of such a row is NaN, so the first NaN of the output is that row's first bin)."""
+    x = _rand((6, 512), dtype, seed=3)
+    x[4, 100] = np.nan
+    x[2, 300] = complex(1.0, np.nan)
+    x[1, 7] = 50.0  # a finite giant earlier in memory must not win
+    amax, flat = dev.absmax_argmax(dev.to_device(x))
+    assert flat == int(np.argmax(np.abs(x))) == 2 * 512 + 300 and np.isnan(amax)
+    for n_in, n_out in ((512, 1024), (512, 512), (4096, 8192)):  # hot kernel / generic persistent kernels
+        f = _rand((9, n_in), dtype, seed=n_in)
+        f[5, n_in // 3] = np.nan
+        f[7, 1] = np.nan
+        for value_only in (False, True):
+            res = dev.pipeline_fused(dev.to_device(f), n_out, want_out=False, want_argmax=True, argmax_value_only=value_only)
+            amax, flat = dev.argmax_reduce(res.absmax2, res.argidx, n_out)
+            assert flat // n_out == 5 and np.isnan(amax), (n_in, n_out, value_only, flat)
+            if not value_only:
+                assert flat == 5 * n_out  # all bins of row 5 are NaN: the first one
+
+
+def test_arg_max_key_path_matches_the_per_row_path(dev):
+    """XM_AMAX_GLOBAL_KEY / xm_row_l1's key / xm_argmax_key_take against the per-row outputs + xm_argmax_reduce:
+    same winner (first row on equal values), key cleared for its next producer."""
+    import torch
+
+    nb, n_in, n_out = 3000, 1024, 2048
+    x = _rand((nb, n_in), "complex64", seed=11)
+    x[1717] *= 3.0
+    x[2900] = x[1717]  # an exact tie: the lower row must win
+    xd = dev.to_device(x)
+    w = torch.linspace(1.0, 0.2, n_out, device="cuda")
+    ref = dev.pipeline_fused(xd, n_out, window=w, want_argmax=True, argmax_value_only=True)
+    amax_ref, flat_ref = dev.argmax_reduce(ref.absmax2, ref.argidx, n_out)
+    key = dev.new_argmax_key("cuda")
+    gmax, gflat = torch.empty(1, device="cuda"), torch.empty(1, dtype=torch.int64, device="cuda")
+    for _ in range(2):  # twice: the key must come back cleared
+        res = dev.pipeline_fused(xd, n_out, window=w, phase_ramp=(0.3, 0.001), global_key=key)
+        dev.argmax_key_take(key, n_out, gmax, gflat)
+        assert int(gflat.item()) // n_out == flat_ref // n_out == 1717
+        assert abs(float(gmax.item()) ** 0.5 - amax_ref) <= 1e-6 * amax_ref
+        assert int(key.abs().max().item()) == 0
+    # ... or the kernel's last workgroup decodes into a pinned record itself
+    rec = dev.new_key_result()
+    for _ in range(2):
+        dev.pipeline_fused(xd, n_out, window=w, phase_ramp=(0.3, 0.001), global_key=key, key_result=rec)
+        torch.cuda.synchronize()
+        m2, fl = dev.read_key_result(rec)
+        assert fl == 1717 * n_out and abs(m2 ** 0.5 - amax_ref) <= 1e-6 * amax_ref and int(key.abs().max().item()) == 0
+    # the guess kernel's key against its per-row norms, and the gather in the same launch
+    norms = dev.row_l1(xd, w, 0, n_used=768, sub_step=2)
+    dev.row_l1(xd, w, 0, out=None, n_used=768, sub_step=2, key=key)
+    row = dev.argmax_key_take(key, n_out, gmax, gflat, xd)
+    best = int(torch.argmax(norms).item())
+    assert int(gflat.item()) == best * n_out and float(gmax.item()) == float(norms[best].item())
+    np.testing.assert_array_equal(row.cpu().numpy()[0], x[best].astype(np.complex128))
+
+
+def test_phase_ramp_equals_phase_table(dev):
+    """xm_pipeline_fused_ramp against xm_pipeline_fused with the table of the same ramp: the native (factorised) path of
+    the hot kernel on every half-length plan, and the expand-to-scratch-table path elsewhere (no zero fill, odd
+    lengths, complex128)."""
+    import torch
+
+    for dtype, n_in, n_out, pad in (("complex64", 4096, 8192, 0), ("complex64", 2048, 4096, 0), ("complex64", 1000, 2048, 0),
+                                    ("complex64", 400, 1024, 0), ("complex64", 1001, 2048, 0), ("complex64", 1536, 1536, 0),
+                                    ("complex64", 1000, 4096, 24), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0)):
+        x = dev.to_device(_rand((37, n_in), dtype, seed=n_in + n_out))
+        rd = torch.float32 if dtype == "complex64" else torch.float64
+        w = torch.linspace(1.0, 0.1, n_out, device="cuda", dtype=rd)
+        a, b = 0.4321, -0.0123
+        table = torch.from_numpy(np.exp(1j * (a + b * np.arange(n_out)))).to("cuda", x.dtype)
+        ref = dev.pipeline_fused(x, n_out, pad, window=w, phase_table=table).out.cpu().numpy()
+        got = dev.pipeline_fused(x, n_out, pad, window=w, phase_ramp=(a, b)).out.cpu().numpy()
+        native = dev.ramp_native(x, n_out, pad)
+        assert native == (dtype == "complex64" and n_in % 2 == 0 and pad % 2 == 0 and 2 * (pad + n_in) <= n_out), (dtype, n_in, n_out, pad)
+        assert _relerr(got, ref) < (1e-6 if dtype == "complex64" else 1e-13), (dtype, n_in, n_out, pad, native)
+
+
+def test_tensor_on_a_non_current_device(dev):
+    """The library's caches are per device: a tensor that lives on another GPU than the current one must be
+    transformed there (tables allocated on ITS device), not through the current device's tables."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    x = _rand((8, 1024), "complex64", seed=1)
+    with torch.cuda.device(0):
+        y1 = dev.fft(dev.to_device(x, "cuda:1"), 1).cpu().numpy()
+    assert _relerr(y1, np.fft.fft(x.astype(np.complex128), norm="ortho")) < TIGHT["complex64"]
+
+
+def test_baseline_als_needs_four_points(dev):
+    import torch
+
+    from xmris_amd import _lib
+
+    with pytest.raises(_lib.XmrisHipError):
+        dev.baseline_als(torch.zeros((2, 3), dtype=torch.float64, device="cuda"), 1, 1e3, 0.01, 3)

@@ -11,6 +11,13 @@
 
 #include <type_traits>
 
+// result record of a global arg-max key (xmris_hip.h: xm_argmax_result)
+struct XmKeyResult {
+  float max2;
+  float pad_;
+  long long flat;
+};
+
 #define XM_KEY_SLOTS 64
 #define XM_KEY_STRIDE 16  // 64-bit words between partial keys (128 bytes)
 
@@ -46,6 +53,7 @@ struct PipeArgs {
   // waves leave a kernel within microseconds and one address takes ~90 atomics per microsecond), all zero at launch;
   // k_key_take merges and clears them.
   unsigned long long* gkey;
+  XmKeyResult* key_result;  // optional (kernels with a row queue): the last workgroup decodes + clears the key itself
   double ramp_db;
   T ramp_e[2];
   T ramp_c[32];

@@ -251,11 +251,40 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
                 ((unsigned long long)best_key << 32) | (unsigned long long)(0xffffffffu - best_row));
   }
   if constexpr (QUEUE) {  // the last workgroup out leaves the counters at zero for the next launch
+    if constexpr (AMAX) {
+      // ... and, asked to (A.key_result), merges the partial keys into the caller's result record: every wave's
+      // atomic is acknowledged (vmcnt) before its workgroup counts itself out, so the last one sees them all
+      if (A.gkey && A.key_result) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    unsigned last = 0;
     if (t == 0) {
       const unsigned d = atomicAdd(A.queue + 1, 1u);
-      if (d == gridDim.x - 1u) {
+      last = d == gridDim.x - 1u;
+      if (last) {
         __hip_atomic_store(A.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(A.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if constexpr (AMAX) {
+      if (A.gkey && A.key_result && t < XM_WAVE) {  // first wave (XM_KEY_SLOTS == 64 == one key per lane)
+        last = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
+        if (last) {
+          unsigned long long k = __hip_atomic_load(A.gkey + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(A.gkey + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
+            const unsigned hi = (unsigned)__shfl_xor((int)(k >> 32), m, XM_WAVE), lo = (unsigned)__shfl_xor((int)(unsigned)k, m, XM_WAVE);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            k = o > k ? o : k;
+          }
+          if (t == 0) {
+            A.key_result->max2 = __uint_as_float((unsigned)(k >> 32));
+            A.key_result->flat = (long long)(0xffffffffu - (unsigned)(k & 0xffffffffu)) * (long long)N;
+          }
+        }
       }
     }
   }

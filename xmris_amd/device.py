@@ -329,14 +329,16 @@ def ramp_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho
 
 def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
                    ortho: bool = True, want_out: bool = True, want_argmax: bool = False, out=None,
-                   absmax2=None, argidx=None, argmax_value_only: bool = False, phase_ramp=None, global_key=None):
+                   absmax2=None, argidx=None, argmax_value_only: bool = False, phase_ramp=None, global_key=None,
+                   key_result=None):
     """One launch of zero-fill + window + FFT(+fftshift) [+ |X|^2 arg-max] [+ phase] on
     ``x2`` = [n_batch, n_in] contiguous rows (FID axis last).  `window` / `phase_table` are
     device tensors of the storage precision (real n_out / complex n_out) or None.
     `phase_ramp` = (phase0, dphase) in radians multiplies output k by e^{i (phase0 + dphase k)} instead of a
     table (phasing.py:62-73 on a uniform axis).  `global_key` (`new_argmax_key`, geometries
     with `ramp_native` only) receives the launch's global arg-max (value bits, row) instead of per-row outputs;
-    `argmax_key_take` decodes and clears it."""
+    `argmax_key_take` decodes and clears it -- or, with `key_result` (`new_key_result`: 16 bytes of pinned host
+    memory), the kernel's last workgroup does that itself and no further launch is needed."""
     _require_device(x2)
     torch = _torch()
     if x2.dim() != 2 or not x2.is_contiguous():
@@ -346,11 +348,12 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
     if want_out and out is None:
         out = torch.empty((nb, n_out), dtype=x2.dtype, device=x2.device)
     if global_key is not None:
-        want_argmax, absmax2, argidx = True, global_key, global_key  # the key rides in the absmax2 slot
+        want_argmax, absmax2 = True, global_key  # the key rides in the absmax2 slot, the result record in argidx's
+        argidx = key_result
     if want_argmax:
         if absmax2 is None:
             absmax2 = torch.empty(nb, dtype=rd, device=x2.device)
-        if argidx is None:
+        if argidx is None and global_key is None:
             argidx = torch.empty(nb, dtype=torch.int32, device=x2.device)
     flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
     if global_key is not None:
@@ -364,14 +367,14 @@ def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=N
             "xm_pipeline_fused_ramp", x2.data_ptr(), n_in, out.data_ptr(),
             window.data_ptr() if window is not None else None, float(phase_ramp[0]), float(phase_ramp[1]), nb, n_in,
             n_out, pad_left, flags, absmax2.data_ptr() if want_argmax else None,
-            argidx.data_ptr() if want_argmax else None, _dtype_code(x2), _stream(x2))
+            argidx.data_ptr() if (want_argmax and argidx is not None) else None, _dtype_code(x2), _stream(x2))
         return FusedResult(out, absmax2 if want_argmax else None, argidx if want_argmax else None)
     _lib.call(
         "xm_pipeline_fused", x2.data_ptr(), n_in, out.data_ptr() if want_out else None,
         window.data_ptr() if window is not None else None,
         phase_table.data_ptr() if phase_table is not None else None, nb, n_in, n_out, pad_left, flags,
-        absmax2.data_ptr() if want_argmax else None, argidx.data_ptr() if want_argmax else None,
-        _dtype_code(x2), _stream(x2))
+        absmax2.data_ptr() if want_argmax else None,
+        argidx.data_ptr() if (want_argmax and argidx is not None) else None, _dtype_code(x2), _stream(x2))
     return FusedResult(out if want_out else None, absmax2 if want_argmax else None,
                        argidx if want_argmax else None)
 
@@ -400,6 +403,16 @@ def row_l1(x2, window=None, pad_left: int = 0, out=None, n_used: int | None = No
 def new_argmax_key(device):
     """A zeroed arg-max key buffer (XM_KEY_BYTES) for `row_l1(key=)` / `pipeline_fused(global_key=)`."""
     return _torch().zeros(8192 // 8, dtype=_torch().int64, device=device)
+
+
+def new_key_result():
+    """Pinned host record (xm_argmax_result: float32 max |X|^2, pad, int64 flat index) a kernel can fill directly."""
+    return _torch().zeros(2, dtype=_torch().int64, pin_memory=True)
+
+
+def read_key_result(rec):
+    """(max |X|^2, flat index) of a `new_key_result` record (after the producing launch has completed)."""
+    return float(rec.view(_torch().float32)[0].item()), int(rec[1].item())
 
 
 def argmax_key_take(key, n_per_row: int, gmax, gflat, x2=None, out_row=None):

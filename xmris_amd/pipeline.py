@@ -390,6 +390,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             # arrays, no separate reductions); every key is cleared by the launch that decodes it
             gkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
             vkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
+            vres=[dev.new_key_result() if use_keys else None for _ in range(ring)],
             sel_slots=[Selection.new_slot(x0, plan, rd) for _ in range(ring)])
     sel = [None] * ring
     events = [dict() for _ in range(n_sets)]
@@ -465,7 +466,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         b = i % ring
         res, ev = results[i], events[i]
         ev["verify_event"].synchronize()
-        tmax, trow = float(bufs["vmax"][b].item()) ** 0.5, int(bufs["vflat"][b].item()) // n
+        if use_keys:
+            m2, fl = dev.read_key_result(bufs["vres"][b])
+            tmax, trow = m2 ** 0.5, fl // n
+        else:
+            tmax, trow = float(bufs["vmax"][b].item()) ** 0.5, int(bufs["vflat"][b].item()) // n
         g_row, owner = rank_offset_rows + trow, 0
         mine = True
         if exchange is not None:
@@ -504,12 +509,17 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     for i in range(n_sets):
         b = i % ring
         ev = events[i]
-        while guessed < min(n_sets - 1, i + g_ahead):  # keep the guess kernels g_ahead datasets in front
-            guessed += 1
-            guess(guessed)
-        while started < min(n_sets - 1, i + s_ahead):  # ... and the searches s_ahead in front
+        # keep the guess kernels g_ahead and the searches s_ahead datasets in front; while the pipeline fills, every
+        # search starts right behind its own guess (the first main pass waits for the first search)
+        while started < min(n_sets - 1, i + s_ahead):
+            while guessed < min(n_sets - 1, started + 1):
+                guessed += 1
+                guess(guessed)
             started += 1
             start_search(started)
+        while guessed < min(n_sets - 1, i + g_ahead):
+            guessed += 1
+            guess(guessed)
         res, fut = pending.pop(i)
         if fut is not None:
             p0, p1, opt = fut.result() if pool is not None else fut
@@ -525,15 +535,14 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["main0"].record()
         if use_keys:
-            main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot, global_key=bufs["vkey"][b])
+            main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot, global_key=bufs["vkey"][b],
+                      key_result=bufs["vres"][b])  # the kernel's last workgroup decodes + clears the key
         else:
             main_pass(plan, inputs[i], outputs[i], res.p0, res.p1, res.pivot, want_argmax=True, absmax2=bufs["tmax"][b],
                       argidx=bufs["tidx"][b], argmax_value_only=True)
         if trace is not None:
             ev["main1"].record()
-        if use_keys:
-            dev.argmax_key_take(bufs["vkey"][b], n, bufs["vmax"][b], bufs["vflat"][b])
-        else:
+        if not use_keys:
             dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
         ev["verify_event"] = torch.cuda.Event()
         ev["verify_event"].record()
