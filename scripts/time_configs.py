@@ -1,4 +1,5 @@
-"""Main-pass timing of the BASELINE.json parity configs (C1, C2, C5) next to C3, c64."""
+"""Pre-pass (per-row maxima, value only) and main-pass (phase ramp where the kernel applies it natively, else a phase
+table) timing of the BASELINE.json parity configs (C1, C2, C5) next to C3, complex64."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmris_amd import device as dev
@@ -7,7 +8,9 @@ def run(name, nv, nt, N):
     w = torch.rand(N, device="cuda"); ph = torch.view_as_complex(torch.randn(N, 2, device="cuda"))
     out = torch.empty(nv, N, dtype=torch.complex64, device="cuda")
     am = torch.empty(nv, device="cuda"); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
-    for label, kw in (("pre ", dict(want_out=False, want_argmax=True)), ("main", dict(want_out=True, phase_table=ph))):
+    native = dev.ramp_native(x, N, 0)
+    for label, kw in (("pre ", dict(want_out=False, want_argmax=True, argmax_value_only=True)),
+                      ("main", dict(want_out=True, phase_ramp=(0.7, 0.0085)) if native else dict(want_out=True, phase_table=ph))):
         f = lambda: dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=am, argidx=ai, **kw)
         for _ in range(3): f()
         torch.cuda.synchronize(); ts = []

@@ -30,8 +30,10 @@ def test_plan_predicates_without_gpu():
     for n in (2, 16, 512, 1024, 2048, 4096, 8192, 1536, 3072, 640, 1531, 1000, 4095):
         assert lib.xm_fft_supported(n, _lib.XM_C64) == 1, n
     assert lib.xm_fft_supported(16384, _lib.XM_C64) == 1
-    assert lib.xm_fft_supported(16384, _lib.XM_C128) == 0
-    assert lib.xm_fft_supported(9001, _lib.XM_C64) == 0  # chirp-z length 32768 has no in-LDS plan
+    assert lib.xm_fft_supported(16384, _lib.XM_C128) == 1  # four-step over global memory (xm_bigfft.inc)
+    assert lib.xm_fft_supported(65536, _lib.XM_C128) == 1 and lib.xm_fft_supported(10007, _lib.XM_C128) == 1
+    assert lib.xm_fft_supported((1 << 22) + 1, _lib.XM_C64) == 0
+    assert lib.xm_fft_supported(9001, _lib.XM_C64) == 1  # chirp-z of length 32768 on top of the four-step path
     assert lib.xm_fft_supported(0, _lib.XM_C64) == 0
 
 

@@ -36,18 +36,20 @@ MIXED = [384, 768, 1536, 3072, 6144, 640, 1280, 2560, 5120]
 BLUESTEIN = [3, 5, 7, 17, 100, 1000, 1531, 2000, 2049, 4095]
 
 
+# beyond the in-LDS plans: four-step over global memory (n = n1 n2), and chirp-z on top of it for everything else
+LONG = [16384, 32768, 65536, 12288, 10240, 24576, 10000, 9001, 20011]
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
-@pytest.mark.parametrize("n", POW2 + MIXED + BLUESTEIN + [16384])
+@pytest.mark.parametrize("n", POW2 + MIXED + BLUESTEIN + LONG)
 def test_fft_matches_numpy(dev, oracle, n, dtype):
-    if n == 16384 and dtype == "complex128":
-        assert not dev.fft_supported(n, complex128=True)
-        return
-    nb = 7 if n > 64 else 37  # ragged vs. spectra-per-workgroup
+    assert dev.fft_supported(n, complex128=dtype == "complex128")
+    nb = (3 if n > 8192 else 7) if n > 64 else 37  # ragged vs. spectra-per-workgroup
     x = _rand((nb, n), dtype, seed=n)
     ref = oracle.fft_values(x.astype(np.complex128), 1)
     got = dev.fft(dev.to_device(x), 1).cpu().numpy()
     assert got.dtype == np.dtype(dtype)
-    tol = TIGHT[dtype] * (4 if n in BLUESTEIN else 1)
+    tol = TIGHT[dtype] * (4 if (n in BLUESTEIN or n in LONG) else 1)
     assert _relerr(got, ref) < tol
 
 
@@ -174,6 +176,10 @@ CASES = [
     (5, 1972, 1972, 0),    # a Bruker FID after the group-delay cut: chirp-z with M = 4096 (k_blue)
     (3, 900, 1000, 50),    # chirp-z with M = 2048, left pad
     (2, 3000, 3001, 0),    # chirp-z with M = 8192 (one-spectrum kernel)
+    (2, 8192, 16384, 0),   # 2x zero fill of an 8k FID: in-LDS for complex64, four-step (128 x 128) for complex128
+    (3, 12000, 32768, 100),  # four-step 128 x 256, left pad
+    (2, 9000, 20000, 0),   # no two-factor split: chirp-z on top of the four-step (M = 65536)
+    (2, 12288, 12288, 0),  # 3 * 2^12 = 8 x 1536
 ]
 
 
@@ -182,8 +188,6 @@ CASES = [
 def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_left, dtype):
     import torch
 
-    if n_out == 16384 and dtype == "complex128":
-        pytest.skip("16384-point complex128 does not fit the LDS (documented limit)")
 
     x = _rand((nb, n_in), dtype, seed=n_in + n_out)
     x128 = x.astype(np.complex128)
@@ -198,7 +202,7 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     rd = torch.float32 if dtype == "complex64" else torch.float64
     wd = torch.from_numpy(w).to("cuda", rd)
     phd = torch.from_numpy(ph).to("cuda", xd.dtype)
-    tol = TIGHT[dtype] * (4 if n_out in (1531, 1972, 1000, 3001) else 1)
+    tol = TIGHT[dtype] * (4 if n_out in (1531, 1972, 1000, 3001, 16384, 32768, 20000, 12288) else 1)
     # (1) arg-max pre-pass only
     pre = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True)
     amax, flat = dev.argmax_reduce(pre.absmax2, pre.argidx, n_out)
@@ -225,7 +229,8 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
 def test_unsupported_length_raises(dev):
     from xmris_amd import _lib
 
-    x = dev.to_device(_rand((2, 9001), "complex64"))
+    assert not dev.fft_supported((1 << 22) + 1) and dev.fft_supported(1 << 22)
+    x = dev.to_device(_rand((1, (1 << 22) + 1), "complex64"))
     with pytest.raises(_lib.UnsupportedLengthError):
         dev.fft(x, 1)
     with pytest.raises(RuntimeError):

@@ -55,11 +55,16 @@ int xm_bluestein_m(int n) {  // smallest power of two >= max(2n-1, 16)
   return m;
 }
 
-bool xm_supported(int n, int dtype) {
+bool xm_supported_in_lds(int n, int dtype) {
   if (n < 2) return false;
   if (xm_has_direct_plan(n, dtype)) return true;
   const int m = xm_bluestein_m(n);
   return xm_has_pow2_plan(m, dtype) || (m == 16384 && dtype == XM_C64);
+}
+
+bool xm_supported(int n, int dtype) {
+  if (xm_supported_in_lds(n, dtype)) return true;
+  return (dtype == XM_C64 ? xm_big_supported_f32(n) : xm_big_supported_f64(n)) != 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,7 +484,7 @@ static int pipeline_common(const void* in, int64_t in_row_stride, void* out, con
   if (flags & ~(XM_FFT_INVERSE | XM_FFT_ORTHO | XM_FFT_SHIFT_IN | XM_FFT_SHIFT_OUT | XM_AMAX_VALUE_ONLY | XM_AMAX_GLOBAL_KEY))
     return fail(XM_ERR_INVALID_ARG, "pipeline: unknown flag bits");
   if (!xm_supported(n_out, dtype))
-    return fail(XM_ERR_UNSUPPORTED_N, "no in-LDS plan for length " + std::to_string(n_out));
+    return fail(XM_ERR_UNSUPPORTED_N, "no plan for length " + std::to_string(n_out));
   hipStream_t st = (hipStream_t)stream;
   DeviceGuard guard(in);
   if (dtype == XM_C64)

@@ -17,7 +17,7 @@ int xm_fail(int code, const std::string& msg);
     }                                                                                \
   } while (0)
 
-enum XmTableKind { TK_TWIDDLE = 0, TK_HALF = 1, TK_CHIRP = 2, TK_CHIRP_FFT = 3 };
+enum XmTableKind { TK_TWIDDLE = 0, TK_HALF = 1, TK_CHIRP = 2, TK_CHIRP_FFT = 3, TK_BIG_WN = 4 };
 
 // Cached device table (kind, n, m, dtype, current device).  `gen` fills re/im in fp64 when the table
 // does not exist yet; it is rounded once to the storage precision and uploaded.
@@ -40,6 +40,11 @@ int xm_pipeline_f32(const void* in, int64_t in_stride, void* out, const void* wi
 int xm_pipeline_f64(const void* in, int64_t in_stride, void* out, const void* window, const void* phase,
                     const double* ramp, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
                     void* absmax2, int32_t* argidx, hipStream_t st);
+// 1 when length n has a path beyond the in-LDS plans (four-step over global memory, xm_bigfft.inc)
+int xm_big_supported_f32(int n);
+int xm_big_supported_f64(int n);
+// ... and whether it has an in-LDS path (direct plan or chirp-z inside the LDS)
+bool xm_supported_in_lds(int n, int dtype);
 // 1 when a geometry has a kernel that applies the ramp natively (no table is built), else 0
 int xm_ramp_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 

@@ -46,6 +46,7 @@ struct PipeArgs {
   int use_ramp;
   int stagger;            // experimental: second half of the grid starts `stagger` x 64 x 127 cycles late
   unsigned* queue;        // persistent kernels with dynamic row hand-out: {head, done} counters, both 0 at launch
+  int queue_chunk;        // ... rows per ticket (>= 1)
   // XM_AMAX_GLOBAL_KEY (complex64, value-only maxima): instead of per-row outputs every wave keeps the best
   // (max |X|^2, row) of the rows it transforms and merges it into this ONE 64-bit key with a single atomic max when
   // it leaves: key = float bits << 32 | (0xffffffff - row), i.e. larger value first, then the lower row.  The key is

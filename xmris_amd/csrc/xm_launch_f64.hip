@@ -8,3 +8,5 @@ int xm_pipeline_f64(const void* in, int64_t in_stride, void* out, const void* wi
   return pipeline_typed(in, in_stride, out, window, phase, ramp, n_batch, n_in, n_out, pad_left, flags, absmax2,
                         argidx, st);
 }
+
+int xm_big_supported_f64(int n) { return big_supported(n) ? 1 : 0; }

@@ -29,7 +29,16 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   int resident = 0;
   rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident);
   if (rc) return rc;
-  const long long blocks = A.n_batch < resident ? A.n_batch : resident;
+  // rows per ticket: about 96 KiB of traffic per chunk (the hot shape's row: 1 -- measured: 2 rows per ticket cost it
+  // 12 %), so that a launch at full speed draws at most ~60 of the ~90 tickets per microsecond one counter sustains
+  const long long row_bytes = (long long)sizeof(Cx<T>) * ((long long)A.n_in + (A.out ? 2 * PL::N : 0));
+  long long chunk = (98304 + row_bytes - 1) / row_bytes;
+  static const int chunk_env = getenv("XM_QUEUE_CHUNK") ? atoi(getenv("XM_QUEUE_CHUNK")) : 0;  // tuning switch
+  if (chunk_env > 0) chunk = chunk_env;
+  chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+  A.queue_chunk = (int)chunk;
+  const long long nchunks = (A.n_batch + chunk - 1) / chunk;
+  const long long blocks = nchunks < resident ? nchunks : resident;
   if constexpr ((MODE & ZF2_AMAX) != 0) {
     // value-only maxima are accumulated with one atomic max per wave: the slots start at +0.0
     if (A.amax_value_only && !A.gkey) HIP_TRY(hipMemsetAsync(A.absmax2, 0, (size_t)A.n_batch * sizeof(T), st));

@@ -112,18 +112,24 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     }
   };
   unsigned best_key = 0, best_row = 0;  // A.gkey: this wave's best (max |X|^2 bits, row), wave-uniform
-  long long s = blockIdx.x;
+  // Work is handed out in CHUNKS of `ch` consecutive rows (one ticket per chunk: a single counter takes ~90 tickets
+  // per microsecond, short rows would outrun it).  c_cur = the chunk being transformed, c_nxt = the one after it
+  // (its first row is prefetched during the last row of c_cur): static stride for the first round, then claimed.
+  const long long ch = A.queue_chunk > 0 ? A.queue_chunk : 1;
+  long long c_cur = blockIdx.x, c_nxt = c_cur + gridDim.x, c_nn = c_nxt + gridDim.x;
+  long long s = c_cur * ch;
+  unsigned off = 0;  // row within the chunk
   if (s < A.n_batch) fetch(s, e0, coff, n_in);
-  // the row whose samples are prefetched during the current transform: static for the first round, then claimed
-  long long s_nxt = s + gridDim.x;
   if constexpr (QUEUE) {
     if (t == 0) *lds_next = atomicAdd(A.queue, 1u) + gridDim.x;
     __syncthreads();
-    s_nxt = (long long)__builtin_amdgcn_readfirstlane((int)*lds_next);
+    c_nxt = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*lds_next);
     __syncthreads();
   }
 
   while (s < A.n_batch) {
+    const bool chunk_end = (off + 1 == (unsigned)ch) || (s + 1 >= A.n_batch);
+    const long long s_nxt = chunk_end ? c_nxt * ch : s + 1;  // the row prefetched during this transform
     // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in ~100 hoisted registers
     unsigned tt = t, cc = col, sh = (unsigned)A.out_shift, nin = n_in, pl = (unsigned)A.pad_left, ee0 = e0;
     asm volatile("" : "+v"(tt));
@@ -159,14 +165,16 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       v[q].im = V{e.im, o.im};
     });
     if (s_nxt < A.n_batch) fetch(s_nxt, ee0, cc - pl, nin);
-    long long s_nn = s_nxt + gridDim.x;
     if constexpr (QUEUE) {
+      // first row of a chunk: thread 0 claims the chunk after next right after the prefetch is issued; the ticket
+      // is back by the last exchange and goes through LDS in front of one of the transform's own barriers
+      const bool claim = off == 0u;  // workgroup-uniform
       unsigned ticket = 0;
-      if (tt == 0u) ticket = atomicAdd(A.queue, 1u) + gridDim.x;  // the row after next; back by the last exchange
+      if (claim && tt == 0u) ticket = atomicAdd(A.queue, 1u) + gridDim.x;
       FFT::run_cols(v, lds, tw, (int)tt, (int)cc, [&]() {
-        if (tt == 0u) *lds_next = ticket;
+        if (claim && tt == 0u) *lds_next = ticket;
       });
-      s_nn = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*lds_next);
+      if (claim) c_nn = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*lds_next);
     } else {
       FFT::run_cols(v, lds, tw, (int)tt, (int)cc);
     }
@@ -242,8 +250,15 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         __builtin_amdgcn_raw_buffer_store_b128(u, rout, t2 * 8u, 0, AUX);
       });
     }
+    if (chunk_end) {
+      c_cur = c_nxt;
+      c_nxt = c_nn;
+      if constexpr (!QUEUE) c_nn = c_nxt + gridDim.x;
+      off = 0;
+    } else {
+      ++off;
+    }
     s = s_nxt;
-    s_nxt = s_nn;
   }
   if constexpr (AMAX) {
     if (A.gkey && best_key != 0u && lane == 0u)
