@@ -46,7 +46,7 @@ def test_invalid_arguments_return_status_not_crash():
     assert lib.xm_pipeline_fused(None, 8, None, None, None, 1, 8, 4, 0, 0, None, None, _lib.XM_C64, None) \
         == _lib.XM_ERR_INVALID_ARG
     assert lib.xm_fft1d_batched(8, 16, 1, (1 << 22) + 1, 0, _lib.XM_C64, None) == _lib.XM_ERR_UNSUPPORTED_N
-    assert b"9001" in lib.xm_last_error_string()
+    assert b"4194305" in lib.xm_last_error_string()
     assert lib.xm_apodize(1, 1, 1, 1, 8, 7, None) == _lib.XM_ERR_INVALID_ARG  # bad dtype
     with pytest.raises(_lib.XmrisHipError):
         _lib.call("xm_roll", 1, 1, 1, 8, 1, _lib.XM_C64, None)  # in == out
