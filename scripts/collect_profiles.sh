@@ -34,6 +34,7 @@ bash scripts/pmc.sh ${tag}guess guess "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE
 bash scripts/pmc.sh ${tag}pre pre "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" > $out/pmc_prepass_kernel.txt
 rm -rf gpurun_out/pmc_${tag}main_* gpurun_out/pmc_${tag}pre_* gpurun_out/pmc_${tag}guess_*
 echo "counters done"
+make -C tools -j4 > /dev/null 2>&1 || true
 ./tools/stream_lab 65536 5 > $out/stream_lab.txt
 ./tools/zf2_lab 65536 7 > $out/zf2_lab.txt
 ./tools/stream_ceiling > $out/stream_ceiling.txt

@@ -23,7 +23,7 @@ kw = {"guess": {}, "write": dict(want_out=True), "pre": dict(want_out=False, wan
       "all": dict(want_out=True, phase_ramp=ramp, global_key=key)}[var]
 for _ in range(int(os.environ.get("REPS", 3))):
     if var == "guess":
-        dev.row_l1(x, w, 0, n_used=2304, sub_step=4, key=key)
+        dev.row_l1(x, w, 0, n_used=2304, sub_step=8, key=key)
         dev.argmax_key_take(key, N, gmax, gflat)
     else:
         dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=None if var == "all" else am, argidx=None if var == "all" else ai, **kw)

@@ -209,7 +209,7 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
 
 
 def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods):
-    """The guess kernel sums every 4th 1-KiB block of the leading samples only.  Row 9 of dataset 1 carries ALL its
+    """The guess kernel sums every 8th 1-KiB block (128 samples) of the leading samples only.  Row 9 of dataset 1 carries ALL its
     signal in blocks the guess skips (samples 128...511: a delayed burst), and the tallest peak of the dataset: the
     full L1 norm would find it, the subset cannot.  The verification must catch it and the repaired result must equal
     the classic schedule's; dataset 0 (ordinary decaying rows) is a hit."""

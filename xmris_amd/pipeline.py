@@ -407,11 +407,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             n_used = int(np.searchsorted(np.cumsum(wabs), (1.0 - 1e-3) * total)) + 1
             n_used = min(plan.n_in, max(256, -(-n_used // 256) * 256))
         plan.extra["guess_n_used"] = n_used
-    # ... and of those, every `sub_step`-th 1-KiB block (whole cache lines spread over the window's support): the
+    # ... and of those, every `sub_step`-th 1-KiB block (default 8: whole cache lines at the start, middle and end of the window's support): the
     # guess is verified by the main pass anyway, and a regular subset ranks rows like the full sum does
     sub_step = plan.extra.get("guess_sub_step")
     if sub_step is None:
-        sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "4")))
+        sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "8")))
     # searches in flight at once share the host: each gets an equal part of the team
     n_workers = min(2, s_ahead) if s_ahead >= 2 else 0
     team = max(1, aps.default_threads() // max(1, n_workers))  # per search in flight
