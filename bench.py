@@ -41,14 +41,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # HBM traffic of ONE launch of the main kernel on the default workload (65,536 x 4096 -> 8192, c64), from the
-# rocprofv3 PMC passes committed in profiles/r01/pmc_main_kernel.txt (separate --pmc runs, scripts/pmc.sh) for the
-# default (speculative) schedule's main kernel, mode 7 = write + phase + per-row maxima:
-# FETCH_SIZE 1,049,751.7 KB -- gfx950 reports a wide coalesced streaming read at exactly half its bytes
-# (MI355X_MICROARCH.md, section HBM), hence x2 -- plus WRITE_SIZE 4,205,141 KB (exact for the 16-byte spectrum
-# stores; the per-wave atomic maxima count as partial lines).  The classic schedule's mode-3 kernel measured
-# 1,049,256 KB / 4,194,304 KB.
-PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049751.7 + 4205141.4) * 1024)
-PMC_SOURCE = "profiles/r01/pmc_main_kernel.txt"
+# rocprofv3 PMC passes committed in profiles/r02/pmc_main_kernel.txt (separate --pmc runs, scripts/pmc.sh) for the
+# default (speculative) schedule's main kernel k_zf2p<..., 13, 11> = write + phase ramp + global arg-max key:
+# FETCH_SIZE 1,049,187.2 KB -- gfx950 reports a wide coalesced streaming read at exactly half its bytes
+# (MI355X_MICROARCH.md, section HBM), hence x2 -- plus WRITE_SIZE 4,197,371.6 KB (exact for 16-byte streaming stores).
+# A constant typed in here, NOT a measurement of the run that prints it (`traffic_static` in the JSON line).
+PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049187.2 + 4197371.6) * 1024)
+PMC_SOURCE = "profiles/r02/pmc_main_kernel.txt"
 
 
 def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, dtype):
