@@ -486,7 +486,7 @@ def cpu_baseline(x, t, N, lb, budget_s, nv_full):
     }
 
 
-def cpu_baseline_threads(x, t, N, lb, nv_full, t_de, n_sample=16384, chunk=64):
+def cpu_baseline_threads(x, t, N, lb, nv_full, t_de, n_sample=32768, chunk=256):
     """the same oracle calls with the voxel axis sharded over the host's cores (numpy's
     pocketfft and ufuncs release the GIL, so a thread pool scales; no fork/exec after the GPU is initialised).
     Wall time of the streaming stages on `n_sample` voxels, projected to the full count, plus the one DE solve."""

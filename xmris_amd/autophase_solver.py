@@ -105,7 +105,10 @@ def default_threads() -> int:
     # overdraws its quota is frozen until the next 100 ms period -- measured as rare 15-25 ms stalls of the whole
     # pipeline with 16 threads on a 16-CPU share, none with 8 (the search takes 0.95 instead of 0.71 ms, still
     # hidden behind the device).
-    share = max(1, cpus // local_world // 2)
+    # Several ranks on one node: only the rank that OWNS a dataset's winning spectrum searches (the others wait,
+    # sleep-polling, for the broadcast), so the team is not divided by the number of ranks -- two cores per rank stay
+    # reserved for launching and polling, the owner's searches may take half of the rest.
+    share = max(1, cpus // 2) if local_world == 1 else max(1, (cpus - 2 * local_world) // 2)
     team = 1
     while team * 2 <= min(16, share):
         team *= 2

@@ -435,6 +435,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                            key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
 
     full_team = aps.default_threads()
+    try:  # the one search that fills the pipeline may borrow (almost) every core for its ~0.7 ms
+        fill_team = max(full_team, min(16, len(os.sched_getaffinity(0)) - 2)) if exchange is None else full_team
+    except AttributeError:
+        fill_team = full_team
 
     def search(sl, k, pivot, threads):
         return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads)
@@ -457,7 +461,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         if mine:
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
             # at a time and have two device periods each
-            th = full_team if j == 0 else team
+            th = fill_team if j == 0 else team
             fut = pool.submit(search, sl, int(k), res.pivot, th) if pool is not None else search(sl, int(k), res.pivot, th)
         pending[j] = (res, fut)
 
