@@ -241,6 +241,38 @@ def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods):
         assert float((outs[k] - refs[k]).abs().max()) < 1e-6 * scale, k
 
 
+@pytest.mark.parametrize("dtype,nt,target", [("complex128", 1024, 2048), ("complex64", 1536, 1536), ("complex64", 1000, 2048)])
+def test_speculative_schedule_on_the_table_and_per_row_paths(mods, dtype, nt, target):
+    """The speculative schedule where the hot kernel does not apply (complex128; no zero fill, mixed radix): per-row
+    maxima + reductions instead of arg-max keys, a phase table instead of the ramp -- same results as the classic
+    schedule, hits and a repair."""
+    import torch
+
+    dev, pipe = mods
+    nv = 40
+    t = np.arange(nt) * 2e-4
+    sets = []
+    for k in range(3):
+        x, _ = _three_peak(nv, nt, 2e-4, seed=700 + k)
+        x[(3 * k + 1) % nv] *= 2.0
+        if k == 2:  # thirty well separated unit lines: largest L1 norm, not the tallest peak
+            x *= 0.05
+            x[7] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * (-2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)) * t) for j in range(30))
+            x[20] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -400.0 * t)
+        sets.append(dev.to_device(x.astype(dtype)))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=sets[0].dtype, device="cuda") for _ in sets]
+    refs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, refs, plan)
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["hit", "hit", "repaired"] and got[2].flat_index // target == 20
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert (a.flat_index, a.target_idx, a.pivot, a.p0, a.p1) == (b.flat_index, b.target_idx, b.pivot, b.p0, b.p1), k
+        tol = 2.5e-7 if dtype == "complex64" else 1e-15
+        assert float((outs[k] - refs[k]).abs().max()) <= tol * float(refs[k].abs().max()), k
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` without a launcher must start two rank processes itself (sharing this GPU here, gloo
     instead of RCCL) and report n_gpus == 2; with one visible device and no --share-gpu it must refuse (exit != 0)

@@ -435,10 +435,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                            key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
 
     full_team = aps.default_threads()
-    try:  # the one search that fills the pipeline may borrow (almost) every core for its ~0.7 ms
-        fill_team = max(full_team, min(16, len(os.sched_getaffinity(0)) - 2)) if exchange is None else full_team
-    except AttributeError:
-        fill_team = full_team
+    fill_team = full_team  # (a larger one-off team for the pipeline-filling search bought nothing measurable)
 
     def search(sl, k, pivot, threads):
         return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads)
