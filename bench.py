@@ -201,7 +201,10 @@ def main():
     tt = t[0] + np.arange(N) * (t[1] - t[0])
     freq = np.roll(np.fft.fftfreq(N, d=tt[1] - tt[0]), N // 2)
 
+    # two output buffers, used alternately: a streaming caller's datasets have outputs of their own, and the
+    # verification of step i then need not finish before step i+1's main pass is queued
     out = torch.empty((nv, N), dtype=cdtype, device=device)
+    out_b = torch.empty((nv, N), dtype=cdtype, device=device)
     times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": [], "gen_ms": [], "polish_ms": [], "table_ms": [], "period_ms": []}
     last = {}
 
@@ -230,9 +233,10 @@ def main():
         datasets (the library's software-pipelined executor: with `overlap` the device runs the pre-pass of
         dataset i+1 and the main pass of dataset i-1 while the host searches (p0, p1) for dataset i; every
         step does all of its own work inside this call, nothing is left over or reused).  NB: the same
-        synthetic dataset and output buffer are passed for every step."""
+        synthetic dataset is passed for every step; outputs alternate between two buffers."""
         trace = []
-        results = pipeline.run_stream([x] * n_steps, [out] * n_steps, plan, exchange=exchange if world > 1 else None,
+        results = pipeline.run_stream([x] * n_steps, [out if k % 2 == 0 else out_b for k in range(n_steps)], plan,
+                                      exchange=exchange if world > 1 else None,
                                       broadcast=broadcast if world > 1 else None, rank_offset_rows=rank * nv,
                                       overlap=overlap, trace=trace, speculate=speculate)
         for r in results:

@@ -507,6 +507,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res.speculation = "repaired"
 
     guessed = started = -1
+    unverified = []  # datasets whose main pass is queued and whose guess is not settled yet (ascending)
     for i in range(n_sets):
         b = i % ring
         ev = events[i]
@@ -530,8 +531,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             res.p0, res.p1 = broadcast([res.p0, res.p1], res.owner)
         ev["t_solved"] = ev["t_table"] = time.perf_counter()
         results[i] = res
-        if i > 0:  # dataset i-1's main pass is done (or about to be): settle its guess before outputs are reused
-            verify(i - 1)
+        # Settle earlier guesses: always those two or more datasets back (their main pass finished a device period
+        # ago, so this never waits -- neither for this GPU nor, through the exchange, for another rank's), and at once
+        # any whose output buffer is about to be overwritten (a repair must still find its spectra there).
+        while unverified and (unverified[0] <= i - 2 or any(outputs[j].data_ptr() == outputs[i].data_ptr() for j in unverified)):
+            verify(unverified.pop(0))
         if trace is not None:
             ev["main0"], ev["main1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["main0"].record()
@@ -547,9 +551,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
         ev["verify_event"] = torch.cuda.Event()
         ev["verify_event"].record()
+        unverified.append(i)
         if trace is not None:
             trace.append(ev)
-    verify(n_sets - 1)
+    while unverified:
+        verify(unverified.pop(0))
     return results
 
 
