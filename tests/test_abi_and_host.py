@@ -416,3 +416,31 @@ def test_native_search_vs_scipy_divergence_sweep():
                 assert dp0 < 2e-2 and dp1 < 2e-2, (seed, dp0, dp1)
     print("native vs scipy route per method:", stats)
     assert stats["acme"]["identical"] >= stats["acme"]["n"] - stats["acme"]["polished"]
+
+
+def test_deferred_chain_metadata_matches_materialised_data(monkeypatch):
+    """The recorded (not yet computed) steps of the accessor chain must announce exactly the shape and dtype their
+    data has once computed (numpy's promotion included), keep coordinates / attrs available without computing, and
+    compute on first use -- on the numpy test double of the device layer."""
+    import _numpy_device
+
+    import xmris_amd as xm
+
+    _numpy_device.install(monkeypatch)
+    t = np.linspace(0, 0.1, 50)
+    for dt_in in (np.complex64, np.complex128, np.float32, np.float64):
+        x = (np.random.default_rng(1).standard_normal((3, 50))).astype(dt_in)
+        a = xm.LabeledArray(x, ("v", "time"), {"time": t}, {"k": 1})
+        zf = a.xmr.zero_fill(target_points=128)
+        ap = zf.xmr.apodize_exp(lb=2.0)
+        sp = ap.xmr.to_spectrum()
+        assert zf.is_deferred and ap.is_deferred and sp.is_deferred
+        steps, root = sp.pending_chain()
+        assert [s_[0] for s_ in steps] == ["to_spectrum", "apodize_exp", "zero_fill"] and root is a
+        assert sp.dims == ("v", "frequency") and sp.attrs["apodization_lb"] == 2.0 and len(sp.coords["frequency"]) == 128
+        for node in (zf, ap, sp):
+            shape, dtype = node.shape, node.dtype
+            v = node.values  # computes (and, recursively, its parents)
+            assert not node.is_deferred and v.shape == shape and v.dtype == dtype, (dt_in, shape, dtype, v.dtype)
+    monkeypatch.setenv("XMRIS_AMD_EAGER", "1")
+    assert not xm.LabeledArray(x, ("v", "time"), {"time": t}).xmr.zero_fill(target_points=128).is_deferred

@@ -159,3 +159,53 @@ def test_xarray_roundtrip_if_installed(xm, oracle):
     sp = xm.to_spectrum(da)
     assert isinstance(sp, xr.DataArray) and sp.dims == ("frequency",) and sp.attrs == {"B0": 3.0}
     np.testing.assert_allclose(sp.values, np.fft.fftshift(np.fft.fft(x, norm="ortho")), atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_lazy_chain_is_fused_by_autophase(xm, oracle, monkeypatch, dtype):
+    """the four chained accessor calls of the quick start record themselves and `autophase`
+    runs the fused kernels on the root -- the staged zero-fill / apodise / FFT kernels are never launched, the
+    intermediates stay unmaterialised -- with the result of the eager chain (dims, coords, attrs, dtype, values) and
+    the oracle's (p0, p1).  Looking at an intermediate materialises it (and the chain falls back to the staged calls)."""
+    from xmris_amd import device as dev
+
+    nv, nt = 24, 1024
+    rng = np.random.default_rng(12)
+    t = np.arange(nt) * 2e-4
+    amp = 0.5 + rng.random(nv)
+    amp[7] = 3.0
+    x = (amp[:, None] * (np.exp(-25 * t) * np.exp(2j * np.pi * 410 * t) + 0.4 * np.exp(-35 * t) * np.exp(-2j * np.pi * 900 * t))[None, :]
+         + 0.02 * (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt)))).astype(dtype)
+    a, o = _pair(xm, oracle, x, ("voxel", "time"), {"voxel": np.arange(nv), "time": t}, {"MHz": 120.0})
+    calls = {"zero_fill": 0, "apodize": 0, "fft": 0}
+    for name in calls:
+        real = getattr(dev, name)
+        monkeypatch.setattr(dev, name, (lambda real, name: lambda *a_, **k_: (calls.__setitem__(name, calls[name] + 1), real(*a_, **k_))[1])(real, name))
+    zf = a.xmr.zero_fill(target_points=2048)
+    ap = zf.xmr.apodize_exp(lb=5.0)
+    sp = ap.xmr.to_spectrum()
+    assert zf.is_deferred and ap.is_deferred and sp.is_deferred and sp.shape == (nv, 2048) and sp.dtype == np.complex128
+    got = sp.xmr.autophase()
+    assert calls == {"zero_fill": 0, "apodize": 0, "fft": 0}, calls  # fused: none of the staged kernels ran
+    assert zf.is_deferred and sp.is_deferred                          # ... and nothing was materialised
+    oc = oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=5.0)), peak_width=100)
+    _same(got, oc, 1e-9)
+    assert abs(got.attrs["phase_p0"] - oc.attrs["phase_p0"]) < 1e-6 and abs(got.attrs["phase_p1"] - oc.attrs["phase_p1"]) < 1e-6
+    # the same chain computed eagerly, step by step
+    monkeypatch.setenv("XMRIS_AMD_EAGER", "1")
+    eager = a.xmr.zero_fill(target_points=2048).xmr.apodize_exp(lb=5.0).xmr.to_spectrum().xmr.autophase()
+    monkeypatch.delenv("XMRIS_AMD_EAGER")
+    assert calls["zero_fill"] == 1 and calls["apodize"] == 1 and calls["fft"] == 1
+    _same(got, eager, 1e-9)
+    assert got.attrs == eager.attrs or (abs(got.attrs["phase_p0"] - eager.attrs["phase_p0"]) < 1e-6)
+    # an intermediate that was looked at is real data from then on; the rest of the chain still works
+    sp2 = a.xmr.zero_fill(target_points=2048).xmr.apodize_exp(lb=5.0).xmr.to_spectrum()
+    _same(sp2, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=5.0)), 1e-9)  # .values
+    assert not sp2.is_deferred
+    _same(sp2.xmr.autophase(), oc, 1e-9)
+    # without a zero fill, and a chain the pattern does not cover (apodize_lg): staged
+    two = a.xmr.apodize_exp(lb=5.0).xmr.to_spectrum()
+    assert two.is_deferred
+    _same(two.xmr.autophase(), oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(o, lb=5.0)), peak_width=100), 1e-9)
+    lg = a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum().xmr.autophase()
+    _same(lg, oracle.autophase(oracle.to_spectrum(oracle.apodize_lg(o, lb=1.0, gb=2.0)), peak_width=100), 1e-9)

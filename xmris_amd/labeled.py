@@ -49,14 +49,29 @@ def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda")
 
 
+class Deferred:
+    """Array data that has not been computed yet (the lazy accessor chain): `thunk()` produces
+    it on first use, `shape` / `dtype` are known up front (all metadata of the hot path is host arithmetic on
+    coordinates), `step` = (operation name, its parameters) and `parent` = the LabeledArray it was applied to.  A
+    consumer that recognises a whole recorded chain -- `autophase` on `to_spectrum(apodize_exp(zero_fill(fid)))` -- runs
+    the fused kernels on the root instead and the intermediates are never materialised."""
+
+    __slots__ = ("thunk", "shape", "dtype", "step", "parent")
+
+    def __init__(self, thunk, shape, dtype, step, parent):
+        self.thunk, self.shape, self.dtype, self.step, self.parent = thunk, tuple(shape), np.dtype(dtype), step, parent
+
+
 class LabeledArray:
     def __init__(self, data, dims, coords=None, attrs=None, name=None):
-        if not _is_tensor(data):
-            data = np.asarray(data)
-        self.data = data
+        self._lazy = None
+        if isinstance(data, Deferred):
+            self._lazy, self._data = data, None
+        else:
+            self._data = data if _is_tensor(data) else np.asarray(data)
         self.dims = tuple(str(d) for d in dims)
-        if len(self.dims) != len(self.data.shape):
-            raise ValueError(f"{len(self.dims)} dims for data of shape {tuple(self.data.shape)}")
+        if len(self.dims) != len(self.shape):
+            raise ValueError(f"{len(self.dims)} dims for data of shape {tuple(self.shape)}")
         self.coords = {}
         for k, c in (coords or {}).items():
             if isinstance(c, Coordinate):
@@ -65,17 +80,42 @@ class LabeledArray:
                 c = Coordinate(c[0], c[1], c[2] if len(c) == 3 else None)
             else:
                 c = Coordinate(k, c)
-            if c.dim in self.dims and len(c.values) != self.data.shape[self.dims.index(c.dim)]:
+            if c.dim in self.dims and len(c.values) != self.shape[self.dims.index(c.dim)]:
                 raise ValueError(f"coordinate {k!r} has {len(c.values)} points, dim {c.dim!r} has "
-                                 f"{self.data.shape[self.dims.index(c.dim)]}")
+                                 f"{self.shape[self.dims.index(c.dim)]}")
             self.coords[str(k)] = c
         self.attrs = dict(attrs or {})
         self.name = name
 
+    # ---- data: computed on first use when deferred ----------------------------------------------
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = self._lazy.thunk()
+            self._lazy = None  # the recorded chain (and its references to the parents) is no longer needed
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data, self._lazy = value, None
+
+    @property
+    def is_deferred(self) -> bool:
+        return self._data is None
+
+    def pending_chain(self):
+        """([(operation, parameters), ...] newest first, root): the recorded, not yet computed operations that lead
+        to this array and the LabeledArray they start from (itself when nothing is pending)."""
+        steps, node = [], self
+        while node._data is None:
+            steps.append(node._lazy.step)
+            node = node._lazy.parent
+        return steps, node
+
     # ---- xarray-like surface ------------------------------------------------------------------
     @property
     def shape(self):
-        return tuple(self.data.shape)
+        return self._lazy.shape if self._data is None else tuple(self._data.shape)
 
     @property
     def ndim(self):
@@ -87,13 +127,15 @@ class LabeledArray:
 
     @property
     def dtype(self):
-        if _is_tensor(self.data):
-            return np.dtype(str(self.data.dtype).replace("torch.", ""))
-        return self.data.dtype
+        if self._data is None:
+            return self._lazy.dtype
+        if _is_tensor(self._data):
+            return np.dtype(str(self._data.dtype).replace("torch.", ""))
+        return self._data.dtype
 
     @property
     def is_device_resident(self) -> bool:
-        return _is_tensor(self.data)
+        return self._data is None or _is_tensor(self._data)  # deferred results are produced in HBM
 
     @property
     def values(self) -> np.ndarray:
@@ -159,7 +201,7 @@ class LabeledArray:
         return XmrisAccessor(self)
 
     def __repr__(self):
-        where = "HBM" if _is_tensor(self.data) else "host"
+        where = "deferred" if self._data is None else ("HBM" if _is_tensor(self._data) else "host")
         return (f"<xmris_amd.LabeledArray {self.sizes} {self.dtype} [{where}] coords={list(self.coords)} "
                 f"attrs={list(self.attrs)}>")
 

@@ -4,7 +4,32 @@ from __future__ import annotations
 import numpy as np
 
 from .. import device as dev
-from ..labeled import Coordinate, LabeledArray, as_labeled, like_input  # noqa: F401
+from ..labeled import Coordinate, Deferred, LabeledArray, as_labeled, like_input  # noqa: F401
+
+
+def lazy_enabled() -> bool:
+    """The hot path's three array steps (zero_fill, apodize_exp, to_spectrum) record themselves instead of running
+    when this is on (default); `XMRIS_AMD_EAGER=1` makes every call compute at once."""
+    import os
+
+    return not os.environ.get("XMRIS_AMD_EAGER")
+
+
+def deferred(src: LabeledArray, compute, shape, dtype, step):
+    """`compute()` now (eager mode) or a `Deferred` that runs it on first use."""
+    if not lazy_enabled():
+        return compute()
+    return Deferred(compute, shape, dtype, step, src)
+
+
+def promoted_dtype(dt):
+    """numpy's result dtype of (array of dtype `dt`) * (float64 / complex128 operand), see promote_for_float64_operand."""
+    import os
+
+    dt = np.dtype(dt)
+    if os.environ.get("XMRIS_AMD_KEEP_COMPLEX64"):
+        return dt
+    return {np.dtype(np.complex64): np.dtype(np.complex128), np.dtype(np.float32): np.dtype(np.float64)}.get(dt, dt)
 
 
 def device_data(da: LabeledArray):

@@ -13,8 +13,8 @@ import numpy as np
 from .. import device as dev
 from ..config import ATTRS, COORDS, DIMS
 from ..dims import _check_dims, term_attrs
-from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
-                      maybe_real, promote_for_float64_operand)
+from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, deferred, device_data, like_input,
+                      maybe_real, promote_for_float64_operand, promoted_dtype)
 from .fourier import fft, fftshift, ifft, ifftshift
 
 
@@ -44,13 +44,15 @@ def to_fid(da, dim: str = DIMS.frequency, out_dim: str = DIMS.time):
     return like_input(out, da)
 
 
-def _apodize(src: LabeledArray, dim: str, weight: np.ndarray) -> LabeledArray:
-    x, was_real = device_data(src)
-    x = promote_for_float64_operand(x)  # complex64 * float64 window -> complex128 (fid.py:136-139)
-    y = maybe_real(dev.apodize(x, src.get_axis_num(dim), weight), was_real)
-    out = src.copy(data=y)
-    out.name = binary_op_name(src, dim)
-    out.attrs = _copy.copy(src.attrs)
+def _apodize(src: LabeledArray, dim: str, weight: np.ndarray, step=None) -> LabeledArray:
+    def compute():
+        x, was_real = device_data(src)
+        x = promote_for_float64_operand(x)  # complex64 * float64 window -> complex128 (fid.py:136-139)
+        return maybe_real(dev.apodize(x, src.get_axis_num(dim), weight), was_real)
+
+    # the result's dtype follows numpy's promotion; a recorded step lets `autophase` fuse the chain (phasing.py)
+    y = deferred(src, compute, src.shape, promoted_dtype(src.dtype), step) if step is not None else compute()
+    out = LabeledArray(y, src.dims, src.coords, _copy.copy(src.attrs), binary_op_name(src, dim))
     return out
 
 
@@ -59,7 +61,7 @@ def apodize_exp(da, dim: str = DIMS.time, lb: float = 1.0):
     src = as_labeled(da)
     _check_dims(src, dim, "apodize_exp")
     t = src.coords[dim].values  # KeyError when `dim` has no coordinate, like the reference
-    out = _apodize(src, dim, np.exp(-np.pi * lb * t))
+    out = _apodize(src, dim, np.exp(-np.pi * lb * t), step=("apodize_exp", {"dim": dim, "lb": lb}))
     out.attrs[ATTRS.apodization_lb] = lb
     return like_input(out, da)
 
@@ -94,8 +96,13 @@ def zero_fill(da, dim: str = DIMS.time, target_points: int = 1024, position: str
         pad_left = pad // 2
     else:
         raise ValueError("`position` must be either 'end' or 'symmetric'.")
-    x, was_real = device_data(src)
-    y = maybe_real(dev.zero_fill(x, src.get_axis_num(dim), int(target_points), pad_left), was_real)
+    def compute():
+        x, was_real = device_data(src)
+        return maybe_real(dev.zero_fill(x, src.get_axis_num(dim), int(target_points), pad_left), was_real)
+
+    shape = tuple(int(target_points) if d == dim else s_ for d, s_ in zip(src.dims, src.shape))
+    y = deferred(src, compute, shape, src.dtype,
+                 ("zero_fill", {"dim": dim, "target_points": int(target_points), "position": position}))
     coords = {}
     for k, c in src.coords.items():
         if c.dim != dim:

@@ -11,7 +11,7 @@ import numpy as np
 from .. import device as dev
 from ..config import COORDS, DIMS
 from ..dims import _check_dims, term_attrs
-from ._common import Coordinate, LabeledArray, as_labeled, device_data, like_input, maybe_real
+from ._common import Coordinate, LabeledArray, as_labeled, deferred, device_data, like_input, maybe_real
 
 
 def _as_list(dim):
@@ -55,9 +55,17 @@ def _transform(da, dim, out_dim, inverse: bool, name: str, shift_in: bool, shift
         raise ValueError("`dim` and `out_dim` lists must have the same length.")
     for d in dims:  # fourier.py:93 reads da.coords[dim]: KeyError without a coordinate
         src.coords[d]
-    x, _ = device_data(src)
-    for d in dims:
-        x = dev.fft(x, src.get_axis_num(d), inverse=inverse, ortho=True, shift_in=shift_in, shift_out=shift_out)
+    def compute():
+        y, _ = device_data(src)
+        for d in dims:
+            y = dev.fft(y, src.get_axis_num(d), inverse=inverse, ortho=True, shift_in=shift_in, shift_out=shift_out)
+        return y
+
+    if len(dims) == 1 and not inverse and shift_out and not shift_in:  # to_spectrum: a step `autophase` can fuse
+        cdt = {np.dtype(np.float32): np.complex64, np.dtype(np.float64): np.complex128}.get(np.dtype(src.dtype), src.dtype)
+        x = deferred(src, compute, src.shape, cdt, ("to_spectrum", {"dim": dims[0], "out_dim": out_dims[0] if out_dims else None}))
+    else:
+        x = compute()
     new_dims = list(src.dims)
     coords = dict(src.coords)
     for i, d in enumerate(dims):

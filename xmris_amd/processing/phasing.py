@@ -61,6 +61,36 @@ def phase(da, dim: str = DIMS.frequency, p0: float = 0.0, p1: float = 0.0, pivot
     return like_input(_phase_labeled(src, x, dim, p0, p1, pivot), da)
 
 
+def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_only, lb):
+    """`autophase` on a spectrum that is still a RECORDED chain to_spectrum(apodize_exp([zero_fill](fid))) along one
+    dim: run the fused kernels (`fused.spectral_pipeline`: two passes over the data instead of six, no intermediate
+    is ever materialised) on the chain's root.  Returns None when the pattern does not apply (anything else was
+    recorded, an intermediate was looked at, the FID axis is not the last one, autophase's own `lb` is set)."""
+    if not src.is_deferred or lb > 0:
+        return None
+    steps, root = src.pending_chain()
+    names = [s_[0] for s_ in steps]
+    if names not in (["to_spectrum", "apodize_exp", "zero_fill"], ["to_spectrum", "apodize_exp"]):
+        return None
+    sp, ap = steps[0][1], steps[1][1]
+    zf = steps[2][1] if len(steps) == 3 else None
+    d0 = sp["dim"]
+    if sp["out_dim"] != dim or ap["dim"] != d0 or (zf is not None and zf["dim"] != d0):
+        return None
+    if d0 not in root.dims or root.get_axis_num(d0) != root.ndim - 1:
+        return None
+    if not np.issubdtype(root.dtype, np.complexfloating):
+        return None
+    from ..fused import spectral_pipeline
+
+    x, _ = device_data(root)
+    base = root.copy(data=promote_for_float64_operand(x))  # the staged chain is complex128 from apodize_exp on
+    n = root.sizes[d0]
+    return spectral_pipeline(base, target_points=zf["target_points"] if zf is not None else n, lb=ap["lb"], dim=d0,
+                             out_dim=dim, position=zf["position"] if zf is not None else "end", method=method,
+                             peak_width=peak_width, target_coord=target_coord, p0_only=p0_only)
+
+
 def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "single",
               peak_width: float = 0.5, target_coord: float | None = None, p0_only: bool = False,
               lb: float = 0.0, temp_time_dim: str = DIMS.time, **kwargs):
@@ -74,6 +104,11 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
         )
     elif mode != "single":
         raise ValueError("Mode must be 'single' or 'all'.")
+    if method not in aps.METHODS:
+        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    fused = _fused_chain(src, dim, method, peak_width, target_coord, p0_only, lb)
+    if fused is not None:
+        return like_input(fused, da)
 
     coords = src.coords[dim].values
     x, _ = device_data(src)
