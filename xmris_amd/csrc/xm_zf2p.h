@@ -7,9 +7,9 @@
 //     k = base_q + 2t (+1) for butterfly q of thread t, so it factorises into (per-thread) x (wave-uniform per q):
 //     the per-thread factor e^{i b 2t} is folded into the last stage's register twiddles once per launch (one extra
 //     complex multiply per spectrum), the odd bins' extra e^{i b} into the odd half's input rotation W_N^col (free),
-//     and the wave-uniform e^{i(a + b base_q)} comes from the kernel arguments (SGPR operands of four packed ops).  No phase-table loads in the loop: k_zf2 issued one 16-byte L2 load per output pair
-//     (as many bytes L2 -> CU as the whole HBM write stream) and every such load had to wait, in vmcnt order, for the
-//     stores issued before it;
+//     and the wave-uniform e^{i(a + b base_q)} comes from the kernel arguments (SGPR operands of four packed ops).
+//     No phase-table loads in the loop: k_zf2 issued one 16-byte L2 load per output pair (as many bytes L2 -> CU
+//     as the whole HBM write stream) and every such load had to wait, in vmcnt order, for the stores issued before it;
 //   * ZF2P_LOAD16: 16-byte FID loads.  Lanes 0-31 of a wave load (x[c], x[c+1]) of row 2j, lanes 32-63 the same
 //     columns of row 2j+1; one v_permlane32_swap per dword pair hands each lane the two rows of its own column.
 //     The stage-0 column of lane l is therefore 64w + 2(l mod 32) + l/32 instead of 64w + l (stage 0 has no
