@@ -166,22 +166,32 @@ def main():
     host_group = None
     shm = None
     rccl_ranks = None
+    rccl_group = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node: the container hostname may not resolve
+        # The default group is gloo: the O(1) arg-max exchange and (p0, p1) broadcast are host-side metadata and must
+        # not queue behind the kernels of other datasets already on the GPU stream.  RCCL carries the barrier and the
+        # max-over-ranks timing in a group of its own; should it fail to come up (every rank learns of it through
+        # gloo), the run goes on with gloo alone and says so in the JSON line instead of dying without a number.
+        dist.init_process_group("gloo")
+        host_group = dist.group.WORLD
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # RCCL: barrier / timing reductions
-        else:
-            dist.init_process_group(args.dist_backend)
-        # the O(1) arg-max exchange and (p0, p1) broadcast are host-side metadata: a gloo group keeps
-        # them from queueing behind the kernels of other datasets already on the GPU stream
-        host_group = dist.new_group(backend="gloo")
-        if args.dist_backend == "nccl":  # how many ranks RCCL really spans (an all_reduce of ones)
-            ones = torch.ones(1, dtype=torch.int32, device=device)
-            dist.all_reduce(ones)
-            rccl_ranks = int(ones.item())
+            ok = 1
+            try:
+                rccl_group = dist.new_group(backend="nccl", device_id=device)
+                ones = torch.ones(1, dtype=torch.int32, device=device)
+                dist.all_reduce(ones, group=rccl_group)  # how many ranks RCCL really spans
+                rccl_ranks = int(ones.item())
+            except Exception as e:  # noqa: BLE001 -- anything RCCL throws at start-up
+                print(f"[rank {rank}] RCCL group unavailable ({e!r}); barrier and timing go through gloo", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                rccl_group, rccl_ranks = None, None
         # on one node the same exchange goes through a shared-memory page (microseconds instead of two
         # loopback collectives per dataset); every rank must agree on the choice, so failures are gathered
         if args.exchange == "shm":
@@ -263,7 +273,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if rccl_group is not None:
+                dist.barrier(group=rccl_group, device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # A full (generation-2) garbage collection over the interpreter's ~10^5 long-lived objects (torch, numpy) takes
@@ -287,8 +300,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if rccl_group is not None else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=rccl_group)
         elapsed = float(tmax.item())
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -360,8 +373,8 @@ def main():
                         if speculate else {"enabled": False}),
         "prime_ms": args.prime_ms,
     }
-    if rccl_ranks is not None:
-        result["rccl_ranks"] = rccl_ranks
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks  # None: the barrier / timing reduction ran on gloo (see stderr)
     if not args.no_footnotes and world == 1:
         result.update(footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms, alg_bytes))
 
