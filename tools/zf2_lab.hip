@@ -69,7 +69,6 @@ std::vector<Cx<float>> twiddles() {
 int main(int argc, char** argv) {
   const long rows = argc > 1 ? atol(argv[1]) : 65536;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
-  const int stagger = argc > 3 ? atoi(argv[3]) : 1;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
@@ -124,7 +123,6 @@ int main(int argc, char** argv) {
   A.out_shift = N / 2;
   A.amax_value_only = 1;
   A.scale = (float)(1.0 / std::sqrt((double)N));
-  A.stagger = stagger;
   unsigned* dqueue;
   CK(hipMalloc(&dqueue, 256));
   CK(hipMemset(dqueue, 0, 256));

@@ -42,9 +42,7 @@ struct PipeArgs {
   // Linear output phase e^{i (a + b k)} (k = output index after the roll) in factorised form, for kernels whose
   // output index is (wave-uniform base_q) + 2t + (0 | 1): ramp_c[2q], ramp_c[2q+1] = e^{i (a + b base_q)} (re, im),
   // ramp_e = e^{i b} (fp64 on the host, rounded once), ramp_db = b; the per-thread factor e^{i b 2t} is computed
-  // in fp64 by the kernel once per launch.  use_ramp != 0 selects it (the table pointer is unused).
-  int use_ramp;
-  int stagger;            // experimental: second half of the grid starts `stagger` x 64 x 127 cycles late
+  // in fp64 by the kernel once per launch (kernels instantiated with ZF2_RAMP; the table pointer is unused then).
   unsigned* queue;        // persistent kernels with dynamic row hand-out: {head, done} counters, both 0 at launch
   int queue_chunk;        // ... rows per ticket (>= 1)
   // XM_AMAX_GLOBAL_KEY (complex64, value-only maxima): instead of per-row outputs every wave keeps the best

@@ -72,7 +72,6 @@ int launch_plan(PipeArgs<T> A, const double* ramp, hipStream_t st) {
     A.ramp_e[0] = (T)std::cos(ramp[1]);
     A.ramp_e[1] = (T)std::sin(ramp[1]);
     A.ramp_db = ramp[1];
-    A.use_ramp = 1;
     A.phase = nullptr;
     return am ? launch_mode<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX, kOptWrite>(A, st)
               : launch_mode<PL, ZF2_WRITE | ZF2_RAMP, kOptWrite>(A, st);

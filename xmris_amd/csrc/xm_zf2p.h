@@ -28,7 +28,7 @@
 #include "xm_kernels.h"
 
 enum { ZF2_RAMP = 8 };                                  // MODE bit (with ZF2_WRITE): phase given as a linear ramp
-enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_STAGGER = 4, ZF2P_QUEUE = 8 };  // OPT bits
+enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8 };  // OPT bits
 
 constexpr int xm_ilog2(int v) {
   int s = 0;
@@ -83,10 +83,6 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     w[q] = ok ? (A.window ? A.window[col + NT * q] * A.scale : A.scale) : T(0);
   }
   __syncthreads();
-  if constexpr ((OPT & ZF2P_STAGGER) != 0) {
-    if (blockIdx.x >= gridDim.x / 2)
-      for (int i = 0; i < A.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   // FID sample j = col + NT*q of a row lives at row[j - pad_left]; positions outside the acquired samples read a
   // clamped (valid) address and are zeroed by their window weight.

@@ -80,9 +80,3 @@ def binary_op_name(da: LabeledArray, dim: str):
     """xarray keeps a binary op's name only when both operands share it; the other operand here is
     the coordinate of `dim` (named `dim`)."""
     return da.name if da.name == dim else None
-
-
-def replace_dim_coords(da: LabeledArray, dim: str, new_len: int):
-    """Coordinates of the result: those along other dims unchanged, those along `dim` dropped
-    (the caller re-creates the dimension coordinate)."""
-    return {k: c for k, c in da.coords.items() if c.dim != dim}
