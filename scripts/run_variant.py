@@ -4,23 +4,27 @@ VARIANT:
   main  = main pass of the classic schedule: k_zf2p mode 9 (write + phase ramp)
   table = write + phase TABLE (k_zf2p mode 3; the first-generation kernel with XM_ZF2_GEN1=1)
   write = write only;  pre = arg-max pre-pass of the classic schedule
-  guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass"""
+  guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass
+  rows  = write + phase ramp + per-row maxima (value only): the complex128 main pass of the speculative schedule
+DTYPE=c128 runs the complex128 kernels (use NV=32768)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmris_amd import device as dev
 nv, nt, N = int(os.environ.get("NV", 65536)), int(os.environ.get("NT", 4096)), int(os.environ.get("NOUT", 8192))
 var = os.environ.get("VARIANT", "all")
-x = torch.view_as_complex(torch.randn(nv, nt, 2, device="cuda"))
-w = torch.rand(N, device="cuda")
-ph = torch.view_as_complex(torch.randn(N, 2, device="cuda"))
-out = torch.empty(nv, N, dtype=torch.complex64, device="cuda")
-am = torch.empty(nv, device="cuda"); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
+rd = torch.float64 if os.environ.get("DTYPE", "c64") == "c128" else torch.float32
+x = torch.view_as_complex(torch.randn(nv, nt, 2, device="cuda", dtype=rd))
+w = torch.rand(N, device="cuda", dtype=rd)
+ph = torch.view_as_complex(torch.randn(N, 2, device="cuda", dtype=rd))
+out = torch.empty(nv, N, dtype=x.dtype, device="cuda")
+am = torch.empty(nv, device="cuda", dtype=rd); ai = torch.empty(nv, dtype=torch.int32, device="cuda")
 key = dev.new_argmax_key("cuda")
 gmax = torch.empty(1, device="cuda"); gflat = torch.empty(1, dtype=torch.int64, device="cuda")
 ramp = (0.7, 0.0085)
 kw = {"guess": {}, "write": dict(want_out=True), "pre": dict(want_out=False, want_argmax=True, argmax_value_only=True),
       "table": dict(want_out=True, phase_table=ph), "main": dict(want_out=True, phase_ramp=ramp),
-      "all": dict(want_out=True, phase_ramp=ramp, global_key=key)}[var]
+      "all": dict(want_out=True, phase_ramp=ramp, global_key=key),
+      "rows": dict(want_out=True, phase_ramp=ramp, want_argmax=True, argmax_value_only=True)}[var]
 for _ in range(int(os.environ.get("REPS", 3))):
     if var == "guess":
         dev.row_l1(x, w, 0, n_used=2304, sub_step=8, key=key)

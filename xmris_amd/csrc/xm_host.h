@@ -47,6 +47,7 @@ int xm_big_supported_f64(int n);
 bool xm_supported_in_lds(int n, int dtype);
 // 1 when a geometry has a kernel that applies the ramp natively (no table is built), else 0
 int xm_ramp_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
+int xm_ramp_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 
 // {head, done} counter pair (zero) for one launch of a persistent kernel that hands out rows dynamically; the
 // kernel's last workgroup leaves it zero again.  Slots come from a per-device ring of 1024.

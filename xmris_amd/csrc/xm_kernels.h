@@ -169,6 +169,74 @@ XM_DEV void amax_reduce_store(T bv, int bi, int t, bool live, long long s, T* ab
   }
 }
 
+
+// =================================================================================================
+// Chunked dynamic hand-out of work items (rows) to the workgroups of a persistent kernel -- k_zf2p's row queue
+// (xm_zf2p.h) as a helper, used by the first-generation kernel k_zf2 (complex128).  One ticket = `ch` consecutive
+// items; the first round is static (chunk = blockIdx.x); at the first item of every chunk thread 0 claims the chunk
+// AFTER next, the ticket returns while the transform runs and is published through LDS in front of one of the
+// transform's own barriers (BlockFFT's hook).  queue == nullptr: plain static stride.
+// Per iteration:  next_item() -> prefetch;  ticket = claim(t);  FFT(hook: publish(t, ticket));  collect();  ...;  advance().
+// After the loop: finish(t).
+// =================================================================================================
+struct WorkQueue {
+  unsigned* q;
+  unsigned* slot;  // one LDS word
+  long long n, ch, c_cur, c_nxt, c_nn, item;
+  unsigned off;
+  XM_DEV void init(unsigned* queue, int chunk, unsigned* lds_slot, long long n_items, unsigned t) {
+    q = queue;
+    slot = lds_slot;
+    n = n_items;
+    ch = chunk > 0 ? chunk : 1;
+    c_cur = blockIdx.x;
+    c_nxt = c_cur + gridDim.x;
+    c_nn = c_nxt + gridDim.x;
+    off = 0;
+    item = c_cur * ch;
+    if (q) {
+      if (t == 0) *slot = atomicAdd(q, 1u) + gridDim.x;
+      __syncthreads();
+      c_nxt = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*slot);
+      __syncthreads();
+    }
+  }
+  XM_DEV bool chunk_end() const { return (off + 1 == (unsigned)ch) || (item + 1 >= n); }
+  XM_DEV long long next_item() const { return chunk_end() ? c_nxt * ch : item + 1; }  // may be >= n: nothing left
+  XM_DEV unsigned claim(unsigned t) const {
+    unsigned ticket = 0;
+    if (q && off == 0u && t == 0u) ticket = atomicAdd(q, 1u) + gridDim.x;
+    return ticket;
+  }
+  XM_DEV void publish(unsigned t, unsigned ticket) const {
+    if (q && off == 0u && t == 0u) *slot = ticket;
+  }
+  XM_DEV void collect() {  // after the transform's barriers
+    if (q && off == 0u) c_nn = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*slot);
+  }
+  XM_DEV void advance() {
+    const long long nx = next_item();
+    if (chunk_end()) {
+      c_cur = c_nxt;
+      c_nxt = c_nn;
+      if (!q) c_nn = c_nxt + gridDim.x;
+      off = 0;
+    } else {
+      ++off;
+    }
+    item = nx;
+  }
+  XM_DEV void finish(unsigned t) const {  // the last workgroup out leaves the counters at zero for the next launch
+    if (q && t == 0u) {
+      const unsigned d = atomicAdd(q + 1, 1u);
+      if (d == gridDim.x - 1u) {
+        __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+};
+
 // =================================================================================================
 // Generic fused kernel.  blockDim = NT * SPB, one spectrum per NT threads.
 // =================================================================================================
@@ -304,7 +372,14 @@ XM_DEV void static_for(F&& f) {
 // MODE bits: 1 = write the spectrum, 2 = multiply by the phase table, 4 = per-spectrum arg-max.
 // ZF2_VALUE_ONLY: the arg-max part is compiled WITHOUT the first-index scan (complex128 write + arg-max modes: the
 // scan's live state pushed them over 256 VGPRs); the runtime flag PipeArgs::amax_value_only alone only skips it.
-enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4, ZF2_VALUE_ONLY = 16 };
+// ZF2_RAMP (with ZF2_WRITE, instead of ZF2_PHASE): the output phase is a linear ramp given in factorised form
+// (PipeArgs::ramp_*), see xm_zf2p.h.  ZF2_PAIR (complex128): both half transforms ride through ONE pass of the
+// block FFT as a two-lane element (32-byte exchange elements, half the barriers) instead of one after the other.
+enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4, ZF2_RAMP = 8, ZF2_VALUE_ONLY = 16, ZF2_PAIR = 32 };
+template <class T, int MODE>
+constexpr bool zf2_paired() {
+  return sizeof(T) == 4 || (MODE & ZF2_PAIR) != 0;
+}
 
 // waves per SIMD the register allocator must leave room for: two resident workgroups per CU
 template <class T, class PL>
@@ -319,25 +394,34 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
   constexpr unsigned N = 2 * PL::N, NT = PL::NT;
   constexpr int P = PL::P;
   constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  constexpr bool RAMP = (MODE & ZF2_RAMP) != 0;
+  static_assert(!(PHASE && RAMP) && (!RAMP || WRITE), "a ramp replaces the phase table of a writing mode");
   // float: the two half-FFTs ride in the two lanes of the packed-f32 VALU (lane x: even bins, lane y:
   // odd bins).  double: no packed f64 math exists, so the halves run one after the other through a
   // 16-byte-element exchange buffer (padded every 16 elements so that two workgroups fit the LDS).
   constexpr bool PACKED = sizeof(T) == 4;
   using V = typename std::conditional<PACKED, typename PairOf<T>::type, T>::type;
-  using FFT = BlockFFT<V, PL, PACKED ? -1 : 4>;
-  using HT = HotTw<T, PL>;
+  using FFT = BlockFFT<V, PL>;
+  using HT = HotTw<T, PL, RAMP>;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
   Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
   T* red_v = reinterpret_cast<T*>(mid + HT::mid_size());  // own region: the loop reuses `lds` at once
   int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
+  unsigned* wq_slot = reinterpret_cast<unsigned*>(red_i + NT / XM_WAVE + 1);
   const unsigned t = threadIdx.x;
 
   HT tw;
   tw.mid = mid;
   tw.load(A.tw, (int)t);
   for (unsigned i = t; i < (unsigned)HT::mid_size(); i += NT) mid[i] = A.tw[i];
-  const Cx<T> rot = A.aux[t];  // W_N^t
+  Cx<T> rot = A.aux[t];  // W_N^t
+  if constexpr (RAMP) {  // e^{i b 2t} into the last-stage twiddles, the odd bins' e^{i b} into their rotation (xm_zf2p.h)
+    double sn, cs;
+    sincos(A.ramp_db * (double)(2u * t), &sn, &cs);
+    tw.fold(mk<T>((T)cs, (T)sn));
+    rot = rot * mk<T>(A.ramp_e[0], A.ramp_e[1]);
+  }
   const unsigned n_in = (unsigned)A.n_in;
   const unsigned toff = t - (unsigned)A.pad_left;  // wraps for t < pad_left -> fails the range test
   T w[P];  // window sample * FFT scale; 0 outside the acquired samples (the zero fill)
@@ -370,14 +454,16 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
   constexpr unsigned CB = sizeof(Cx<T>);
   const unsigned last_in = n_in - 1u;
   Cx<T> xr[P];
-  long long s = blockIdx.x;
-  if (s < A.n_batch) {
-    const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
+  WorkQueue wq;
+  wq.init(A.queue, A.queue_chunk, wq_slot, A.n_batch, t);
+  if (wq.item < A.n_batch) {
+    const Cx<T>* __restrict__ row = A.in + wq.item * A.in_stride;
 #pragma unroll
     for (int q = 0; q < P; ++q) xr[q] = row[min(toff + NT * q, last_in)];
   }
 
-  for (; s < A.n_batch; s += gridDim.x) {
+  for (; wq.item < A.n_batch; wq.advance()) {
+    const long long s = wq.item;
     // Opaque copies: every LDS / global address below is a cheap function of (t, shift, n_in).  Without
     // this the compiler hoists all of them out of the persistent loop (they are loop-invariant) and
     // pays for it with >100 live VGPRs/SGPRs; recomputing them per spectrum costs a few ALU ops.
@@ -388,7 +474,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     asm volatile("" : "+s"(pl));
     const unsigned toff2 = tt - pl;
     auto prefetch = [&]() {  // the next FID, while the current one is transformed
-      const long long s2 = s + gridDim.x;
+      const long long s2 = wq.next_item();
       if (s2 < A.n_batch) {
         const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
         if (nin == NT * P && pl == 0u) {
@@ -441,7 +527,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         h[q] = mul_w<q, 2 * P, T>((xr[q] * w[q]) * rot);
       });
       prefetch();
-      FFT::run(h, lds, tw, (int)tt);
+      const unsigned ticket = wq.claim(tt);
+      FFT::run_cols(h, lds, tw, (int)tt, (int)tt, [&]() { wq.publish(tt, ticket); });
+      wq.collect();
       reduce_half(1u);
       if (A.amax_value_only) bi = 0;
       amax_reduce_store<T, (int)NT>(bv, bi, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
@@ -473,8 +561,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
       }
     });
     prefetch();
-
-    FFT::run(v, lds, tw, (int)tt);
+    const unsigned ticket = wq.claim(tt);
+    FFT::run_cols(v, lds, tw, (int)tt, (int)tt, [&]() { wq.publish(tt, ticket); });
+    wq.collect();
     if constexpr (!PACKED) FFT::run(vo, lds, tw, (int)tt);
     // (even, odd) outputs of butterfly q as scalars
     auto even = [&](int q) -> Cx<T> {
@@ -517,7 +606,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
           bi = min(bi, ((mo == bv) | all_nan) ? k0 + 1 : 0x7fffffff);
         }
       }
-      if constexpr (PACKED && NT > XM_WAVE) {
+      if constexpr (sizeof(T) == 4 && NT > XM_WAVE) {
         if (A.amax_value_only) {
           // value only: one atomic max per wave into the row's slot (zeroed by the launcher; squared magnitudes
           // order like their bit patterns) -- no LDS slot, no workgroup barrier
@@ -534,14 +623,23 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
     if constexpr (WRITE) {
       Cx<T>* __restrict__ orow = A.out + s * (long long)N;
       const __amdgpu_buffer_rsrc_t rph = xm_rsrc(A.phase, PHASE ? N * CB : 0u);
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
+      // RAMP: the wave-uniform factors e^{i(a + b base_q)}, re-read from the kernel-argument segment every spectrum
+      typedef const T __attribute__((address_space(4))) * kptr_t;
+      kptr_t rc = (kptr_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                           __builtin_offsetof(PipeArgs<T>, ramp_c));
+      asm volatile("" : "+s"(rc));
+      static_for<0, P>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
         const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
         // this butterfly's 2*NT contiguous outputs: descriptor base = row + base (see buf_store)
         const __amdgpu_buffer_rsrc_t rout = xm_rsrc(orow + base, 2u * NT * CB);
         Cx<T> xe = even(q);
         Cx<T> xo = odd(q);
-        if constexpr (PHASE) {
+        if constexpr (RAMP) {
+          const Cx<T> c = mk<T>(rc[2 * q], rc[2 * q + 1]);
+          xe = xe * c;
+          xo = xo * c;
+        } else if constexpr (PHASE) {
           const CxPair<T> ph = buf_load(rph, t2 * CB, base * CB, (CxPair<T>*)nullptr);
           xe = xe * ph.a;
           xo = xo * ph.b;
@@ -550,9 +648,10 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<T, PL>())) void k_zf2(PipeArgs<T
         o.a = xe;
         o.b = xo;
         buf_store(rout, t2 * CB, o);
-      }
+      });
     }
   }
+  wq.finish(t);
 }
 
 // =================================================================================================

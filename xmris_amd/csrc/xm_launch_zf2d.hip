@@ -1,0 +1,63 @@
+// Instantiation + launch of k_zf2d (xm_zf2d.h), the complex128 kernel of the hot shape (4096 -> 8192).  Its own
+// translation unit so that it compiles in parallel with the other kernels.
+#include "xm_host.h"
+#include "xm_plans.h"
+#include "xm_tables.h"
+#include "xm_zf2d.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+using T = double;
+using PL = typename PlanOf<4096>::type;  // 256 threads x 16 points, radices 16.16.16
+
+template <int MODE>
+int launch_mode(PipeArgs<T> A, hipStream_t st) {
+  const void* tw = nullptr;
+  int rc = xm_table_get(TK_TWIDDLE, PL::N, PL::NT, XM_C128, xm_gen_twiddles<PL>, nullptr, &tw);
+  if (rc) return rc;
+  A.tw = (const Cx<T>*)tw;
+  if (A.n_batch <= 0) return XM_OK;
+  const size_t lds = (size_t)BlockFFT<T, PL>::lds_elems() * sizeof(Cx<T>) +
+                     (size_t)ChainTw<T, PL, false>::mid_size() * sizeof(Cx<T>) +
+                     ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
+  static XmResidency res;
+  int resident = 0;
+  rc = xm_resident_blocks(res, k_zf2d<PL, MODE>, PL::NT, lds, &resident);
+  if (rc) return rc;
+  // one row (64 KiB in + 128 KiB out) per ticket
+  A.queue_chunk = 1;
+  const long long blocks = A.n_batch < resident ? A.n_batch : resident;
+  rc = xm_queue_slot(&A.queue);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_zf2d<PL, MODE>), dim3((unsigned)blocks), dim3(PL::NT), lds, st, A);
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+}  // namespace
+
+int xm_zf2d_launch(const PipeArgs<double>& A_in, const double* ramp, hipStream_t st, bool* handled) {
+  static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // tuning switch: k_zf2<double>
+  PipeArgs<double> A = A_in;
+  const bool wr = A.out != nullptr, ph = A.phase != nullptr, am = A.absmax2 != nullptr;
+  *handled = !(gen1 || !wr || ph || (am && !A.amax_value_only));
+  if (!*handled) return XM_OK;
+  if (ramp) {
+    // e^{i (a + b k)}, k = base_q + 2t (+1): the wave-uniform factors, and e^{i b} for the odd bins (xm_zf2p.h)
+    constexpr unsigned N = 2 * PL::N;
+    for (int q = 0; q < PL::P; ++q) {
+      const unsigned base = (2u * PL::NT * q + (unsigned)A.out_shift) & (N - 1u);
+      const double a = ramp[0] + ramp[1] * (double)base;
+      A.ramp_c[2 * q] = std::cos(a);
+      A.ramp_c[2 * q + 1] = std::sin(a);
+    }
+    A.ramp_e[0] = std::cos(ramp[1]);
+    A.ramp_e[1] = std::sin(ramp[1]);
+    A.ramp_db = ramp[1];
+    return am ? launch_mode<ZF2_WRITE | ZF2_RAMP | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<ZF2_WRITE | ZF2_RAMP>(A, st);
+  }
+  return am ? launch_mode<ZF2_WRITE | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<ZF2_WRITE>(A, st);
+}

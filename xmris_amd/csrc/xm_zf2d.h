@@ -1,0 +1,163 @@
+// k_zf2d -- the complex128 twin of k_zf2p for the hot shape (4096 -> 8192, ">= 2x end zero fill").
+//
+// k_zf2<double> (xm_kernels.h) runs the 512-thread x 8-point plan at ~180 VGPRs: ONE workgroup per CU, whose eight
+// waves move in lockstep from barrier to barrier -- counters (profiles/r02/pmc_c128_main.txt): VALU issue 15 % of the
+// wave cycles, LDS 28 % busy, 40 % waiting; the arg-max-only pass alone (no stores) takes 1.0 ms of the 1.3-1.4.
+// Nothing overlaps.  Here: the 256-thread x 16-point plan (radices 16.16.16: two exchanges instead of three), TWO
+// workgroups per CU (<= 256 VGPRs each) that fill each other's barrier and load waits.  To fit the registers
+//   * the two half transforms run one after the other through the same 16-byte-element exchange buffer: the even-bin
+//     half is transformed first and kept (64 VGPRs), the odd-bin half is then formed from the still-live samples;
+//   * the 15 last-stage twiddles W_4096^{r t} of a thread are not held (60 VGPRs) but generated as a running product
+//     g, g^2, ... from g = W_4096^t (ChainTw: 15 extra complex multiplies per half, ~1e-15 relative);
+//   * the next row is not prefetched (its 64 VGPRs do not fit beside both halves; tried in front of the epilogue:
+//     190 spilled registers): the other workgroup computes while this one waits for its samples.
+// Measured (32,768 rows, MI355X): write + ramp 1.16 ms = 5.57 TB/s (k_zf2<double>: 1.31 with the ramp, 1.44 with
+// the table), with the per-row maxima 1.21 (1.43 / 1.60).  k_zf2p's conflict-free column remap was tried: LDS
+// conflicts 21 % -> 0 of the LDS cycles, time unchanged (the remapped 16-byte loads fill half a sector per
+// quarter wave) -- the plain columns stay.
+// Rows come from the device-scope queue (xm_kernels.h: WorkQueue), the output phase is the factorised ramp of
+// xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).
+#pragma once
+#include "xm_kernels.h"
+
+// Twiddle source for plans whose last stage is ONE butterfly per thread: middle stages from the LDS copy, the last
+// stage's r-th twiddle as f g^r (f: the folded per-thread unit factor, R0 only), generated in ascending r
+template <class S, class PL, bool R0>
+struct ChainTw {
+  static constexpr bool kHasR0 = R0;
+  static constexpr int K = PL::K;
+  static_assert(K > 1 && PL::P == PL::radix(K - 1), "one last-stage butterfly per thread");
+  static constexpr int mid_size() { return PL::tw_offset(K - 1); }
+  const Cx<S>* mid;
+  Cx<S> g;      // W^{t}: the table's r = 1 entry of this thread's butterfly
+  Cx<S> r0[1];  // f
+  mutable Cx<S> cur;
+  XM_DEV void load(const Cx<S>* __restrict__ tw, int t) { g = tw[PL::tw_offset(K - 1) + t]; }
+  XM_DEV void fold(Cx<S> f) {
+    static_assert(R0, "fold needs the r = 0 slot");
+    r0[0] = f;
+  }
+  template <int ST, int U, int R1>
+  XM_DEV Cx<S> get(int k) const {
+    if constexpr (ST == K - 1) {
+      if constexpr (R1 == 1) {
+        if constexpr (R0) cur = r0[0] * g; else cur = g;
+      } else {
+        cur = cur * g;
+      }
+      return cur;
+    } else {
+      return mid[PL::tw_offset(ST) + (R1 - 1) * PL::ns(ST) + k];
+    }
+  }
+};
+
+template <class PL, int MODE>
+__global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
+  using T = double;
+  constexpr unsigned N = 2 * PL::N, NT = PL::NT;
+  constexpr int P = PL::P;
+  constexpr bool RAMP = (MODE & ZF2_RAMP) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  static_assert((MODE & ZF2_WRITE) && !(MODE & ZF2_PHASE), "writing modes without a phase table");
+  static_assert(!AMAX || (MODE & ZF2_VALUE_ONLY), "maxima: value only");
+  static_assert(NT == 256, "two workgroups of four waves per CU");
+  using FFT = BlockFFT<T, PL>;
+  using TW = ChainTw<T, PL, RAMP>;
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem);
+  Cx<T>* mid = lds + FFT::lds_elems();
+  T* red_v = reinterpret_cast<T*>(mid + TW::mid_size());
+  int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
+  unsigned* wq_slot = reinterpret_cast<unsigned*>(red_i + NT / XM_WAVE + 1);
+  const unsigned t = threadIdx.x;
+
+  TW tw;
+  tw.mid = mid;
+  tw.load(A.tw, (int)t);
+  for (unsigned i = t; i < (unsigned)TW::mid_size(); i += NT) mid[i] = A.tw[i];
+  Cx<T> rot = A.aux[t];  // W_N^t
+  if constexpr (RAMP) {  // e^{i b 2t} into the last stage, the odd bins' e^{i b} into their rotation (xm_zf2p.h)
+    double sn, cs;
+    sincos(A.ramp_db * (double)(2u * t), &sn, &cs);
+    tw.fold(mk<T>(cs, sn));
+    rot = rot * mk<T>(A.ramp_e[0], A.ramp_e[1]);
+  }
+  const unsigned n_in = (unsigned)A.n_in;
+  const unsigned toff = t - (unsigned)A.pad_left;  // wraps for t < pad_left -> fails the range test
+  T w[P];  // window sample * FFT scale; 0 outside the acquired samples (the zero fill)
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const bool ok = (toff + NT * q) < n_in;
+    w[q] = ok ? (A.window ? A.window[t + NT * q] * A.scale : A.scale) : T(0);
+  }
+  __syncthreads();
+
+  constexpr unsigned CB = sizeof(Cx<T>);
+  WorkQueue wq;
+  wq.init(A.queue, A.queue_chunk, wq_slot, A.n_batch, t);
+  for (; wq.item < A.n_batch; wq.advance()) {
+    const long long s = wq.item;
+    // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in hoisted registers
+    unsigned tt = t, sh = (unsigned)A.out_shift, nin = n_in, pl = (unsigned)A.pad_left;
+    asm volatile("" : "+v"(tt));
+    asm volatile("" : "+s"(sh));
+    asm volatile("" : "+s"(nin));
+    asm volatile("" : "+s"(pl));
+    const unsigned toff2 = tt - pl;
+    Cx<T> xr[P];
+    {
+      const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
+      if (nin == NT * P && pl == 0u) {  // exactly half full: no clamp, scalar row base + one 32-bit lane offset
+        const unsigned lane_off = tt * CB;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          xr[q] = *reinterpret_cast<const Cx<T>*>(reinterpret_cast<const char*>(row + NT * q) + lane_off);
+      } else {
+#pragma unroll
+        for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
+      }
+    }
+    const unsigned ticket = wq.claim(tt);  // the chunk after next; back long before the second transform's hook
+
+    Cx<T> e[P], h[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) e[q] = xr[q] * w[q];
+    FFT::run(e, lds, tw, (int)tt);  // even bins: FFT_H(z)
+    static_for<0, P>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      h[q] = mul_w<q, 2 * P, T>((xr[q] * w[q]) * rot);
+    });
+    FFT::run_cols(h, lds, tw, (int)tt, (int)tt, [&]() { wq.publish(tt, ticket); });  // odd bins: FFT_H(z W_N^k)
+    wq.collect();
+
+    const unsigned t2 = 2u * tt;
+    if constexpr (AMAX) {
+      T bv = T(-1);
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        bv = fmax(bv, fmax(e[q].re * e[q].re + e[q].im * e[q].im, h[q].re * h[q].re + h[q].im * h[q].im));
+      bv = amax_nan_if_unset(bv);
+      amax_reduce_store<T, (int)NT>(bv, 0, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+    }
+    Cx<T>* __restrict__ orow = A.out + s * (long long)N;
+    typedef const T __attribute__((address_space(4))) * kptr_t;
+    kptr_t rc = (kptr_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                         __builtin_offsetof(PipeArgs<T>, ramp_c));
+    asm volatile("" : "+s"(rc));
+    static_for<0, P>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
+      const __amdgpu_buffer_rsrc_t rout = xm_rsrc(orow + base, 2u * NT * CB);
+      CxPair<T> o;
+      o.a = e[q];
+      o.b = h[q];
+      if constexpr (RAMP) {
+        const Cx<T> c = mk<T>(rc[2 * q], rc[2 * q + 1]);
+        o.a = o.a * c;
+        o.b = o.b * c;
+      }
+      buf_store(rout, t2 * CB, o);
+    });
+  }
+  wq.finish(t);
+}

@@ -27,7 +27,6 @@
 #pragma once
 #include "xm_kernels.h"
 
-enum { ZF2_RAMP = 8 };                                  // MODE bit (with ZF2_WRITE): phase given as a linear ramp
 enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8 };  // OPT bits
 
 constexpr int xm_ilog2(int v) {
