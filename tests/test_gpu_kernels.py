@@ -487,8 +487,11 @@ def test_phase_ramp_equals_phase_table(dev):
 
     for dtype, n_in, n_out, pad in (("complex64", 4096, 8192, 0), ("complex64", 2048, 4096, 0), ("complex64", 1000, 2048, 0),
                                     ("complex64", 400, 1024, 0), ("complex64", 1001, 2048, 0), ("complex64", 1536, 1536, 0),
-                                    ("complex64", 1000, 4096, 24), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0)):
-        x = dev.to_device(_rand((37, n_in), dtype, seed=n_in + n_out))
+                                    ("complex64", 1000, 4096, 24), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0),
+                                    ("complex128", 2048, 4096, 0), ("complex128", 1001, 2048, 3), ("complex128", 400, 1024, 0),
+                                    ("complex128", 3000, 8192, 24), ("complex128", 2049, 4096, 0)):
+        nb = 2100 if (dtype == "complex128" and n_out <= 4096) else 37  # more rows than the persistent grid's first round
+        x = dev.to_device(_rand((nb, n_in), dtype, seed=n_in + n_out))
         rd = torch.float32 if dtype == "complex64" else torch.float64
         w = torch.linspace(1.0, 0.1, n_out, device="cuda", dtype=rd)
         a, b = 0.4321, -0.0123
