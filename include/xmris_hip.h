@@ -150,9 +150,10 @@ int xm_pipeline_fused(const void* in, int64_t in_row_stride, void* out, const vo
 /* The fused hot path with the autophase ramp in closed form (A8, processing/phasing.py:62-73: on a uniform axis
  * phi[k] = rad(p0) + rad(p1) * (c[k] - pivot) / range is linear in the output index k):
  *   out[b, k] = X[k] * e^{i (phase0 + dphase * k)},   phase0 / dphase in radians, fp64.
- * Everything else as xm_pipeline_fused (`out` must be given).  On the ">= 2x end zero fill" geometries of complex64
- * (xm_pipeline_ramp_native) the kernel applies the ramp in factorised form -- no table exists, nothing is read per
- * output; other geometries expand the ramp into a stream-ordered scratch table first. */
+ * Everything else as xm_pipeline_fused (`out` must be given).  On the ">= 2x end zero fill" geometries
+ * (xm_pipeline_ramp_native: complex64 with 16-byte aligned rows, complex128 always) the kernel applies the ramp in
+ * factorised form -- no table exists, nothing is read per output; other geometries expand the ramp into a
+ * stream-ordered scratch table first. */
 int xm_pipeline_fused_ramp(const void* in, int64_t in_row_stride, void* out, const void* window, double phase0,
                            double dphase, int64_t n_batch, int n_in, int n_out, int pad_left, unsigned flags,
                            void* absmax2, int32_t* argidx, int dtype, void* stream);
