@@ -316,8 +316,8 @@ def main():
         kernel = ("k_zf2p<FftPlan<4096,256,16,16,16>, " + ("13" if speculate else "9") + ", 11>" if hot
                   else "xm_pipeline_fused_ramp main pass")
     else:
-        kernel = ("k_zf2<double, FftPlan<4096,512,8,8,8,8>, " + ("23" if speculate else "3") + ">" if hot
-                  else "xm_pipeline_fused main pass")
+        kernel = ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("29" if speculate else "9") + ">" if hot
+                  else "xm_pipeline_fused_ramp main pass")
     kernel += " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
     static_traffic = (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None)
 
