@@ -1,4 +1,4 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU path: voxel-axis sharding with the O(1) arg-max
+"""world_size-2 (and 4) CPU test (gloo) of the multi-GPU path: voxel-axis sharding with the O(1) arg-max
 exchange and (p0, p1) broadcast of ``xmris_amd.sharding`` -- the same calls bench.py makes over RCCL.
 Per-rank spectra come from numpy here (the kernels need a GPU); the sharding logic is what is tested:
 the sharded result must equal the oracle run on the whole dataset, including an exact tie across ranks."""
@@ -81,14 +81,14 @@ def _worker(rank, world, port, tie, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tie", [False, True])
-def test_two_rank_sharded_pipeline_matches_oracle(oracle, tie):
+@pytest.mark.parametrize("tie,world", [(False, 2), (True, 2), (True, 4)])
+def test_two_rank_sharded_pipeline_matches_oracle(oracle, tie, world):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tie, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tie, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
@@ -97,10 +97,11 @@ def test_two_rank_sharded_pipeline_matches_oracle(oracle, tie):
         assert p.exitcode == 0
     x, t = _dataset(tie)
     ref, info = oracle.pipeline_values(x, t, 512, 5.0, peak_width=100)
-    assert [(g[1], g[2]) for g in got] == [(0, 6), (6, 12)]
+    per = 12 // world
+    assert [(g[1], g[2]) for g in got] == [(r * per, (r + 1) * per) for r in range(world)]
     for g in got:
         assert g[4] == info["flat_idx"]
-        assert g[3] == (0 if tie else 1)
+        assert g[3] == (0 if tie else 8 // per)  # the tie's first occurrence (row 2) lives on rank 0
         assert g[7] == info["pivot"]
         assert abs(g[5] - info["p0"]) < 1e-6 and abs(g[6] - info["p1"]) < 1e-6
     out = np.concatenate([g[8] for g in got], axis=0)
