@@ -290,7 +290,16 @@ def main():
     gc.freeze()
     if args.prime_ms > 0:  # untimed: until the wall clock says the device has been busy for a while
         t_prime = time.perf_counter()
-        while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        while True:
+            # every run_steps is a sequence of exchanges: all ranks must make the SAME number of calls, so rank 0's
+            # clock decides for everyone (each rank reading its own clock left them one call apart -- a deadlock)
+            go = (time.perf_counter() - t_prime) * 1e3 < args.prime_ms
+            if dist is not None:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32)
+                dist.broadcast(flag, src=0, group=host_group)
+                go = bool(flag.item())
+            if not go:
+                break
             run_steps(8, False)
     if args.warmup:
         run_steps(args.warmup, False)

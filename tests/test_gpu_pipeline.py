@@ -285,8 +285,10 @@ def test_bench_self_launches_two_ranks():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # with the wall-clock priming loop on: every rank must leave it after the same number of calls (each call is a
+    # sequence of exchanges; ranks that read their own clocks ended up one call apart and deadlocked)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--voxels", "2048", "--no-cpu-baseline", "--prime-ms", "0"]
+           "--warmup", "1", "--voxels", "2048", "--no-cpu-baseline", "--prime-ms", "60"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
