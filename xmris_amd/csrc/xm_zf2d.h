@@ -19,6 +19,9 @@
 // xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).
 #pragma once
 #include "xm_kernels.h"
+#ifndef XM_ZF2D_AUX
+#define XM_ZF2D_AUX 2
+#endif
 
 // Twiddle source for plans whose last stage is ONE butterfly per thread: middle stages from the LDS copy, the last
 // stage's r-th twiddle as f g^r (f: the folded per-thread unit factor, R0 only), generated in ascending r
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
         o.a = o.a * c;
         o.b = o.b * c;
       }
-      buf_store(rout, t2 * CB, o);
+      buf_store<XM_ZF2D_AUX>(rout, t2 * CB, o);
     });
   }
   wq.finish(t);
