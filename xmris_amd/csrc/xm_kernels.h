@@ -341,13 +341,12 @@ XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, CxPair<float> v) 
   __builtin_memcpy(&u, &v, 16);
   __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
 }
-template <int AUX = 0>  // 2: nontemporal
 XM_DEV void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, CxPair<double> v) {
   xm_u4 u;
   __builtin_memcpy(&u, &v.a, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
   __builtin_memcpy(&u, &v.b, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff + 16u, 0, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff + 16u, 0, 0);
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)

@@ -14,14 +14,12 @@
 // Measured (32,768 rows, MI355X): write + ramp 1.16 ms = 5.57 TB/s (k_zf2<double>: 1.31 with the ramp, 1.44 with
 // the table), with the per-row maxima 1.21 (1.43 / 1.60).  k_zf2p's conflict-free column remap was tried: LDS
 // conflicts 21 % -> 0 of the LDS cycles, time unchanged (the remapped 16-byte loads fill half a sector per
-// quarter wave) -- the plain columns stay.
+// quarter wave) -- the plain columns stay.  Nontemporal stores (k_zf2p: +3 %): 1.16 -> 1.98 ms here -- a lane's 32
+// bytes leave as two 16-byte stores, and without the cache to merge them every sector is written in halves.
 // Rows come from the device-scope queue (xm_kernels.h: WorkQueue), the output phase is the factorised ramp of
 // xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).
 #pragma once
 #include "xm_kernels.h"
-#ifndef XM_ZF2D_AUX
-#define XM_ZF2D_AUX 2
-#endif
 
 // Twiddle source for plans whose last stage is ONE butterfly per thread: middle stages from the LDS copy, the last
 // stage's r-th twiddle as f g^r (f: the folded per-thread unit factor, R0 only), generated in ascending r
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
         o.a = o.a * c;
         o.b = o.b * c;
       }
-      buf_store<XM_ZF2D_AUX>(rout, t2 * CB, o);
+      buf_store(rout, t2 * CB, o);
     });
   }
   wq.finish(t);
