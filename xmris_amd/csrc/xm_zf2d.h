@@ -15,7 +15,8 @@
 // the table), with the per-row maxima 1.21 (1.43 / 1.60).  k_zf2p's conflict-free column remap was tried: LDS
 // conflicts 21 % -> 0 of the LDS cycles, time unchanged (the remapped 16-byte loads fill half a sector per
 // quarter wave) -- the plain columns stay.  Nontemporal stores (k_zf2p: +3 %): 1.16 -> 1.98 ms here -- a lane's 32
-// bytes leave as two 16-byte stores, and without the cache to merge them every sector is written in halves.
+// bytes leave as two 16-byte stores, and without the cache to merge them every sector is written in halves; with
+// neighbouring lanes trading halves first (whole 32-byte sectors per instruction): 1.18 plain, 1.97 nontemporal.
 // Rows come from the device-scope queue (xm_kernels.h: WorkQueue), the output phase is the factorised ramp of
 // xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).
 #pragma once
