@@ -564,3 +564,69 @@ def test_baseline_als_needs_four_points(dev):
 
     with pytest.raises(_lib.XmrisHipError):
         dev.baseline_als(torch.zeros((2, 3), dtype=torch.float64, device="cuda"), 1, 1e3, 0.01, 3)
+
+
+def test_randomised_geometries_of_the_fused_entry_point(dev, oracle):
+    """A seeded sweep over what the parametrised tests pin one at a time: storage precision x transform length
+    (every kernel family) x zero-fill geometry (n_in, pad_left; ragged, odd, full) x batch size (below, at and far
+    above the persistent grid, so static rounds, queue tickets and chunk tails all occur) x {window} x {no phase,
+    table, ramp} x {no maxima, maxima + index, maxima value only} x {fftshift} -- each against numpy in fp64."""
+    import torch
+
+    rng = np.random.default_rng(20240611)
+    lengths = [64, 128, 512, 1024, 2048, 4096, 8192, 384, 768, 1536, 3072, 5120, 1000, 1531, 2000]
+    batches = [1, 2, 3, 17, 255, 512, 513, 1025, 2100]
+    for case in range(120):
+        dtype = "complex64" if rng.random() < 0.5 else "complex128"
+        n_out = int(rng.choice(lengths))
+        kind = rng.integers(0, 4)
+        if kind == 0:  # no zero fill
+            n_in, pad = n_out, 0
+        elif kind == 1:  # exactly 2x
+            n_in, pad = n_out // 2, 0
+        else:  # ragged, possibly shifted
+            n_in = int(rng.integers(1, n_out + 1))
+            pad = int(rng.integers(0, n_out - n_in + 1)) if rng.random() < 0.5 else 0
+        nb = int(rng.choice(batches))
+        if nb * n_out > (1 << 23):  # keep the case small enough for the numpy side
+            nb = max(1, (1 << 23) // n_out)
+        use_w = rng.random() < 0.7
+        phase = ("none", "table", "ramp")[int(rng.integers(0, 3))]
+        amax = ("none", "index", "value")[int(rng.integers(0, 3))]
+        shift = rng.random() < 0.8
+        tag = (case, dtype, nb, n_in, n_out, pad, use_w, phase, amax, shift)
+
+        x = _rand((nb, n_in), dtype, seed=1000 + case)
+        x[nb // 2] *= 2.5
+        xpad = np.zeros((nb, n_out), np.complex128)
+        xpad[:, pad:pad + n_in] = x
+        w = np.exp(-np.linspace(0.0, 2.0, n_out)) if use_w else np.ones(n_out)
+        spec = np.fft.fft(xpad * w, axis=1, norm="ortho")
+        if shift:
+            spec = np.roll(spec, n_out // 2, axis=1)
+        a, b = float(rng.uniform(-3, 3)), float(rng.uniform(-0.01, 0.01))
+        ph = np.exp(1j * (a + b * np.arange(n_out)))
+        ref = spec * ph if phase != "none" else spec
+
+        xd = dev.to_device(x)
+        rd = torch.float32 if dtype == "complex64" else torch.float64
+        kw = dict(shift_out=shift)
+        if use_w:
+            kw["window"] = torch.from_numpy(w).to("cuda", rd)
+        if phase == "table":
+            kw["phase_table"] = torch.from_numpy(ph).to("cuda", xd.dtype)
+        elif phase == "ramp":
+            kw["phase_ramp"] = (a, b)
+        if amax != "none":
+            kw.update(want_argmax=True, argmax_value_only=(amax == "value"))
+        r = dev.pipeline_fused(xd, n_out, pad, **kw)
+        tol = TIGHT[dtype] * (4 if n_out in (1000, 1531, 2000) else 1)
+        assert _relerr(r.out.cpu().numpy(), ref) < tol, tag
+        if amax != "none":  # maxima are taken BEFORE the phase (a unit factor)
+            m = np.sqrt(r.absmax2.cpu().numpy().astype(np.float64))
+            np.testing.assert_allclose(m, np.abs(spec).max(axis=1), rtol=30 * tol, err_msg=str(tag))
+            if amax == "index":
+                idx = r.argidx.cpu().numpy()
+                mag = np.abs(spec)
+                # the device compares in the storage precision: accept any index whose magnitude ties the maximum there
+                assert np.all(mag[np.arange(nb), idx] >= mag.max(axis=1) * (1 - 30 * tol)), tag
