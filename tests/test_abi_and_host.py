@@ -444,3 +444,43 @@ def test_deferred_chain_metadata_matches_materialised_data(monkeypatch):
             assert not node.is_deferred and v.shape == shape and v.dtype == dtype, (dt_in, shape, dtype, v.dtype)
     monkeypatch.setenv("XMRIS_AMD_EAGER", "1")
     assert not xm.LabeledArray(x, ("v", "time"), {"time": t}).xmr.zero_fill(target_points=128).is_deferred
+
+
+def test_lean_polish_is_scipys_minimize_to_the_bit(oracle):
+    """`autophase_solver.polish_lbfgsb` drives scipy's compiled L-BFGS-B core itself (no ScalarFunction / bounds
+    front end) with a restated forward-difference gradient: x, fun, jac, nfev, nit, success must equal
+    `scipy.optimize.minimize(..., method="L-BFGS-B", bounds=...)` -- the polish `differential_evolution` runs for the
+    reference (phasing.py:276-284) -- bit for bit, for all three objectives, one and two parameters, starts inside,
+    ON the bounds (the difference step flips there) and next to them, converged at once or after tens of iterations."""
+    import scipy.optimize
+
+    from xmris_amd import autophase_solver as aps
+
+    rng = np.random.default_rng(3)
+    n_iter = []
+    for case in range(6):
+        nt = int(rng.choice([256, 1024, 2048]))
+        t = np.arange(nt) / 5000.0
+        f0, d, a = rng.uniform(-2000, 2000, 3), rng.uniform(10, 60, 3), rng.uniform(0.2, 1.0, 3)
+        x = sum(ai * np.exp(-di * t) * np.exp(2j * np.pi * fi * t + 1j * rng.uniform(-3, 3)) for ai, di, fi in zip(a, d, f0))
+        x = (x + 0.02 * (rng.standard_normal(nt) + 1j * rng.standard_normal(nt)))[None, :]
+        _, inf = oracle.pipeline_values(x, t, 2 * nt, 5.0, solve=False)
+        sl, fr, pv, ti = inf["slice"], inf["freq"], inf["pivot"], inf["target_idx"]
+        for method in aps.METHODS:
+            obj = aps.NativeObjective(sl, fr, pv, ti, aps.index_width_of(fr, 100), method)
+            for p0_only in (False, True):
+                bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
+                starts = [np.array([rng.uniform(-180, 180)] + ([] if p0_only else [rng.uniform(-4000, 4000)])) for _ in range(2)]
+                starts += [np.array([180.0] + ([] if p0_only else [4000.0])), np.array([-180.0] + ([] if p0_only else [-4000.0])),
+                           np.array([179.999999995] + ([] if p0_only else [12.0]))]
+                for x0 in starts:
+                    ref = scipy.optimize.minimize(obj, np.copy(x0), method="L-BFGS-B", bounds=bounds)
+                    got = aps.polish_lbfgsb(obj, np.copy(x0), bounds)
+                    tag = (case, method, p0_only, x0)
+                    assert np.array_equal(ref.x, got.x) and ref.fun == got.fun and np.array_equal(ref.jac, got.jac), tag
+                    assert (ref.nfev, ref.nit, ref.success, ref.status) == (got.nfev, got.nit, got.success, got.status), tag
+                    n_iter.append(ref.nit)
+    assert max(n_iter) >= 10 and min(n_iter) == 0  # both regimes were exercised
+    # the fallback is the public entry point itself
+    fb = aps.polish_lbfgsb(obj, np.copy(x0), bounds, force_scipy=True)
+    assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev

@@ -166,6 +166,98 @@ class NativeObjective:
             pass
 
 
+def polish_lbfgsb(obj, x0, bounds, force_scipy: bool = False):
+    """`scipy.optimize.minimize(obj, x0, method="L-BFGS-B", bounds=bounds)` -- the polish step of
+    `differential_evolution` (phasing.py:276-284 runs it with scipy's defaults) -- without the per-call Python
+    machinery around it (`ScalarFunction`, bounds standardisation, `approx_derivative`'s generic front end: 0.3-0.5 ms
+    of interpreter time per search, held under the GIL while other searches and the launch thread wait).  Same
+    compiled core (`scipy.optimize._lbfgsb.setulb`), same defaults (maxcor 10, ftol 2.22e-9, gtol 1e-5, eps 1e-8,
+    maxls 20), same forward-difference gradient as `approx_derivative(method="2-point", abs_step=1e-8, bounds=...)`
+    with its exactly-representable step and its flip at the upper bound, same evaluation count (the gradient's
+    evaluations included, the repeated request for f at x0 answered from the cache like `ScalarFunction` does):
+    x, fun, nfev, nit, success are scipy's to the bit (tests/test_abi_and_host.py).  The three points of one
+    f-and-gradient request go to the native objective in ONE call.  Any surprise in scipy's private interface
+    (this follows 1.15.3, the version SURVEY pins) -> the public `minimize`."""
+    import scipy.optimize
+
+    try:
+        if force_scipy:
+            raise ImportError
+        from scipy.optimize import _lbfgsb
+        from scipy.optimize._lbfgsb_py import _minimize_lbfgsb  # noqa: F401 -- same module layout as the code followed
+    except ImportError:
+        return scipy.optimize.minimize(obj, np.copy(x0), method="L-BFGS-B", bounds=bounds)
+    lb = np.array([b[0] for b in bounds], dtype=np.float64)
+    ub = np.array([b[1] for b in bounds], dtype=np.float64)
+    n = len(lb)
+    m, maxls, maxfun, maxiter = 10, 20, 15000, 15000
+    factr = 2.2204460492503131e-09 / np.finfo(float).eps
+    pgtol, abs_step = 1e-5, 1e-8
+    x0 = np.clip(np.asarray(x0, dtype=np.float64).ravel(), lb, ub)
+    state = {"nfev": 0, "x": None, "f": None, "g": None}
+
+    def func_and_grad(x):
+        if state["x"] is not None and np.array_equal(x, state["x"]):
+            return state["f"], state["g"]
+        xc = np.array(x, dtype=np.float64)
+        # approx_derivative: absolute step, relative fallback when it vanishes, flipped where it leaves the bounds
+        sign = (xc >= 0).astype(float) * 2 - 1
+        h = np.full(n, abs_step)
+        h = np.where(((xc + h) - xc) == 0, np.finfo(np.float64).eps ** 0.5 * sign * np.maximum(1.0, np.abs(xc)), h)
+        lower, upper = xc - lb, ub - xc
+        xt = xc + h
+        violated = (xt < lb) | (xt > ub)
+        fitting = np.abs(h) <= np.maximum(lower, upper)
+        h[violated & fitting] *= -1
+        forward = (upper >= lower) & ~fitting
+        h[forward] = upper[forward]
+        backward = (upper < lower) & ~fitting
+        h[backward] = -lower[backward]
+        pts = np.tile(xc, (n + 1, 1))
+        dx = np.empty(n)
+        for i in range(n):
+            pts[1 + i, i] += h[i]
+            dx[i] = pts[1 + i, i] - xc[i]  # the step as an exactly representable number
+        vals = obj.score_batch(pts)
+        state["nfev"] += n + 1
+        f = float(vals[0])
+        g = (vals[1:] - f) / dx
+        state.update(x=xc, f=f, g=g)
+        return f, g
+
+    func_and_grad(x0)  # ScalarFunction evaluates f and the gradient at x0 when it is built
+    nbd = np.full(n, 2, dtype=np.int32)
+    x = np.array(x0, dtype=np.float64)
+    f = np.array(0.0, dtype=np.int32)
+    g = np.zeros((n,), dtype=np.int32)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+    iwa = np.zeros(3 * n, dtype=np.int32)
+    task = np.zeros(2, dtype=np.int32)
+    ln_task = np.zeros(2, dtype=np.int32)
+    lsave = np.zeros(4, dtype=np.int32)
+    isave = np.zeros(44, dtype=np.int32)
+    dsave = np.zeros(29, dtype=np.float64)
+    nit = 0
+    try:
+        while True:
+            g = g.astype(np.float64)
+            _lbfgsb.setulb(m, x, lb, ub, nbd, f, g, factr, pgtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)
+            if task[0] == 3:
+                f, g = func_and_grad(x)
+            elif task[0] == 1:
+                nit += 1
+                if nit >= maxiter:
+                    task[0], task[1] = 5, 504
+                elif state["nfev"] > maxfun:
+                    task[0], task[1] = 5, 502
+            else:
+                break
+    except (TypeError, ValueError):  # another scipy: its private entry point takes other arguments
+        return scipy.optimize.minimize(obj, np.copy(x0), method="L-BFGS-B", bounds=bounds)
+    return scipy.optimize.OptimizeResult(x=x, fun=f, jac=g, nfev=state["nfev"], nit=nit, success=bool(task[0] == 4),
+                                         status=0 if task[0] == 4 else (1 if (state["nfev"] > maxfun or nit >= maxiter) else 2))
+
+
 def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None):
     """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
     run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective
@@ -183,7 +275,7 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, t
     t1 = time.perf_counter()
     # the polish's isolated evaluations below run serially (the pool is parked outside xm_solver_de)
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
-    res = scipy.optimize.minimize(obj, np.copy(x), method="L-BFGS-B", bounds=bounds)
+    res = polish_lbfgsb(obj, np.copy(x), bounds)
     nfev += res.nfev
     lo = np.array([b[0] for b in bounds])
     hi = np.array([b[1] for b in bounds])

@@ -473,6 +473,10 @@ int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, do
 // A search takes a free pool for its duration; with every pool taken it evaluates serially.
 void xm_solver_pool_begin(int threads) {
   Pool* p = nullptr;
+  if (threads <= 1) {  // a serial search needs no team: any number of them may run side by side
+    t_pool = nullptr;
+    return;
+  }
   {
     std::lock_guard<std::mutex> lk(g_pools_mu);
     for (int i = 0; i < kPools && !p; ++i) {

@@ -352,6 +352,30 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
     return results
 
 
+def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: int):
+    """(searches in flight, threads per search) for the streaming executor.  A search is O(1) per dataset on the host
+    (measured, n_out = 8192, ACME: 3.2 / 1.9 / 1.1 / 0.76 ms of generations with 1 / 2 / 4 / 8 threads + 0.3 ms of
+    polish; generations scale with n_out); the device period is the dataset's compulsory traffic at ~5.5 TB/s plus
+    ~0.12 ms of small launches.  Two searches at a time with half the team each (fewest datasets in flight) where
+    that keeps up with the device; otherwise four with a quarter each (a smaller team spends fewer core-milliseconds
+    per search).  Measured (16-CPU share; ms per step with 2 / 4 / 8 in flight): 16,384 x 2048 -> 4096: 0.73 / 0.60 /
+    0.79, 32,768 x 1536: 0.49 / 0.47 / 0.66, 65,536 x 4096 -> 8192: 1.17 / 1.19 / 1.23 -- eight single-thread searches
+    lose to the interpreter lock (every search ends in scipy's polish, ~0.3 ms of Python)."""
+    import os
+
+    if os.environ.get("XM_SEARCH_WORKERS"):  # tuning switch
+        w = max(2, int(os.environ["XM_SEARCH_WORKERS"]))
+        return w, max(1, threads // w)
+    device_ms = n_rows * (plan.n_in + plan.n_out) * elem_bytes / 5.5e9 + 0.12
+    speedup = {1: 1.0, 2: 1.73, 4: 3.05, 8: 4.25, 16: 5.7}
+    w = 2
+    team = max(1, threads // w)
+    gain = speedup[max(k for k in speedup if k <= team)]
+    if (0.3 + 3.2 * (plan.n_out / 8192.0) / gain) / w > 0.8 * device_ms and threads >= 4:
+        w = 4
+    return w, max(1, threads // w)
+
+
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
                             peak_width, p0_only, trace):
     """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair).
@@ -372,7 +396,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     x0 = inputs[0]
     nb = x0.shape[0]
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
-    s_ahead = (2 if n_sets > 2 else 1) if overlap else 0   # searches running ahead of the main pass being queued
+    # searches running ahead of the main pass being queued (= worker threads): two where the device period is longer
+    # than a search, more -- with smaller teams, which use the cores better -- where the host would pace the steps
+    workers, team = _search_workers(plan, nb, x0.element_size(), aps.default_threads())
+    s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     ring = g_ahead + 2
     use_keys = x0.dtype == torch.complex64 and dev.ramp_native(x0, plan.n_out, plan.pad_left)
@@ -413,13 +440,14 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     if sub_step is None:
         sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "8")))
     # searches in flight at once share the host: each gets an equal part of the team
-    n_workers = min(2, s_ahead) if s_ahead >= 2 else 0
+    n_workers = s_ahead if s_ahead >= 2 else 0
     team = max(1, aps.default_threads() // max(1, n_workers))  # per search in flight
     pool = None
     if n_workers:
-        pool = plan.extra.get("search_pool")
+        pool = plan.extra.get(("search_pool", n_workers))
         if pool is None:
-            pool = plan.extra["search_pool"] = ThreadPoolExecutor(max_workers=2, thread_name_prefix="xm-search")
+            pool = plan.extra[("search_pool", n_workers)] = ThreadPoolExecutor(max_workers=n_workers,
+                                                                              thread_name_prefix="xm-search")
 
     def guess(j):  # streaming L1 norms + the selection stage on the row with the largest one
         b = j % ring
