@@ -52,6 +52,7 @@ rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/tl_c128
     --steps 40 --warmup 5 --no-cpu-baseline --no-footnotes > $out/bench_c128.json 2> $out/bench_c128.err
 python3 scripts/trace_timeline.py $out/tl_c128 40 > $out/timeline_c128.txt
 rm -rf $out/tl_c128
+python3 scripts/time_fill.py > $out/fill_timeline.txt 2>/dev/null || true
 python3 scripts/time_fft_sweep.py > $out/fft_sweep.txt 2>/dev/null || true
 python3 scripts/time_configs.py > $out/time_configs.txt 2>/dev/null || true
 echo "collected into $out"

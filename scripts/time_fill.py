@@ -17,6 +17,7 @@ def run(k):
     torch.cuda.synchronize()
     return t0, e0, trace, res, time.perf_counter() - t0
 for _ in range(3): run(8)
+print("65,536 x 4096 -> 8192 c64, 20 datasets per call, pipeline empty at the start; host clock / device events in ms from the call")
 for rep in range(3):
     t0, e0, trace, res, el = run(20)
     print(f"run {rep}: {el*1e3:.3f} ms for 20 datasets = {el*1e3/20:.4f} ms/step")
