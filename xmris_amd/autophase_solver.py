@@ -178,10 +178,13 @@ def polish_lbfgsb(obj, x0, bounds, force_scipy: bool = False):
     x, fun, nfev, nit, success are scipy's to the bit (tests/test_abi_and_host.py).  The three points of one
     f-and-gradient request go to the native objective in ONE call.  Any surprise in scipy's private interface
     (this follows 1.15.3, the version SURVEY pins) -> the public `minimize`."""
+    import scipy
     import scipy.optimize
 
     try:
-        if force_scipy:
+        # the private entry point is followed as scipy 1.15 has it (SURVEY 8c pins 1.15.3); any other release takes
+        # the public route
+        if force_scipy or not scipy.__version__.startswith("1.15."):
             raise ImportError
         from scipy.optimize import _lbfgsb
         from scipy.optimize._lbfgsb_py import _minimize_lbfgsb  # noqa: F401 -- same module layout as the code followed
