@@ -209,9 +209,13 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     assert flat == int(np.argmax(np.abs(spec)))
     assert abs(amax - np.abs(spec).max()) < 1e-5 * np.abs(spec).max()
     np.testing.assert_array_equal(pre.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
-    # (1b) value-only pre-pass (the bench's mode): same per-spectrum maxima, bit for bit
+    # (1b) value-only pre-pass (the bench's mode): same per-spectrum maxima, bit for bit -- except on the complex128
+    # hot shape, where the value-only modes run another kernel (k_zf2d: 16-point butterflies) than the index modes
     vo = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True, argmax_value_only=True)
-    assert torch.equal(vo.absmax2, pre.absmax2)
+    if dtype == "complex128" and (n_out, pad_left) == (8192, 0) and 2 * n_in <= n_out:
+        assert torch.allclose(vo.absmax2, pre.absmax2, rtol=1e-13, atol=0.0)
+    else:
+        assert torch.equal(vo.absmax2, pre.absmax2)
     # (2) unphased spectrum + arg-max in one launch
     both = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_argmax=True)
     assert _relerr(both.out.cpu().numpy(), spec) < tol

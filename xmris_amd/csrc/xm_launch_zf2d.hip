@@ -43,8 +43,9 @@ int xm_zf2d_launch(const PipeArgs<double>& A_in, const double* ramp, hipStream_t
   static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // tuning switch: k_zf2<double>
   PipeArgs<double> A = A_in;
   const bool wr = A.out != nullptr, ph = A.phase != nullptr, am = A.absmax2 != nullptr;
-  *handled = !(gen1 || !wr || ph || (am && !A.amax_value_only));
+  *handled = !gen1 && !ph && (wr ? (!am || A.amax_value_only) : (am && A.amax_value_only));
   if (!*handled) return XM_OK;
+  if (!wr) return launch_mode<ZF2_AMAX | ZF2_VALUE_ONLY>(A, st);
   if (ramp) {
     // e^{i (a + b k)}, k = base_q + 2t (+1): the wave-uniform factors, and e^{i b} for the odd bins (xm_zf2p.h)
     constexpr unsigned N = 2 * PL::N;

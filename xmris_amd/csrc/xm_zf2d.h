@@ -18,7 +18,10 @@
 // bytes leave as two 16-byte stores, and without the cache to merge them every sector is written in halves; with
 // neighbouring lanes trading halves first (whole 32-byte sectors per instruction): 1.18 plain, 1.97 nontemporal.
 // Rows come from the device-scope queue (xm_kernels.h: WorkQueue), the output phase is the factorised ramp of
-// xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).
+// xm_zf2p.h (ZF2_RAMP) or none; maxima, if asked for, per row and value only (ZF2_AMAX | ZF2_VALUE_ONLY).  Without
+// ZF2_WRITE (the classic schedule's arg-max pre-pass) each half is reduced to its maximum as soon as it is transformed
+// (prefetching the next row beside the second transform still spilled 130 registers: the 16-point butterfly itself
+// needs ~100).
 #pragma once
 #include "xm_kernels.h"
 
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
   using T = double;
   constexpr unsigned N = 2 * PL::N, NT = PL::NT;
   constexpr int P = PL::P;
-  constexpr bool RAMP = (MODE & ZF2_RAMP) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
-  static_assert((MODE & ZF2_WRITE) && !(MODE & ZF2_PHASE), "writing modes without a phase table");
+  constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, RAMP = (MODE & ZF2_RAMP) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  static_assert((WRITE || AMAX) && !(MODE & ZF2_PHASE) && (WRITE || !RAMP), "no phase table; a ramp needs an output");
   static_assert(!AMAX || (MODE & ZF2_VALUE_ONLY), "maxima: value only");
   static_assert(NT == 256, "two workgroups of four waves per CU");
   using FFT = BlockFFT<T, PL>;
@@ -97,6 +100,20 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
   constexpr unsigned CB = sizeof(Cx<T>);
   WorkQueue wq;
   wq.init(A.queue, A.queue_chunk, wq_slot, A.n_batch, t);
+  Cx<T> xr[P];
+  auto fetch = [&](long long s2, unsigned tt, unsigned nin, unsigned pl) {
+    const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
+    if (nin == NT * P && pl == 0u) {  // exactly half full: no clamp, scalar row base + one 32-bit lane offset
+      const unsigned lane_off = tt * CB;
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        xr[q] = *reinterpret_cast<const Cx<T>*>(reinterpret_cast<const char*>(row + NT * q) + lane_off);
+    } else {
+      const unsigned toff2 = tt - pl;
+#pragma unroll
+      for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
+    }
+  };
   for (; wq.item < A.n_batch; wq.advance()) {
     const long long s = wq.item;
     // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in hoisted registers
@@ -105,26 +122,18 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
     asm volatile("" : "+s"(sh));
     asm volatile("" : "+s"(nin));
     asm volatile("" : "+s"(pl));
-    const unsigned toff2 = tt - pl;
-    Cx<T> xr[P];
-    {
-      const Cx<T>* __restrict__ row = A.in + s * A.in_stride;
-      if (nin == NT * P && pl == 0u) {  // exactly half full: no clamp, scalar row base + one 32-bit lane offset
-        const unsigned lane_off = tt * CB;
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-          xr[q] = *reinterpret_cast<const Cx<T>*>(reinterpret_cast<const char*>(row + NT * q) + lane_off);
-      } else {
-#pragma unroll
-        for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
-      }
-    }
+    fetch(s, tt, nin, pl);
     const unsigned ticket = wq.claim(tt);  // the chunk after next; back long before the second transform's hook
 
     Cx<T> e[P], h[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) e[q] = xr[q] * w[q];
     FFT::run(e, lds, tw, (int)tt);  // even bins: FFT_H(z)
+    T bv = T(-1);
+    if constexpr (!WRITE) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) bv = fmax(bv, e[q].re * e[q].re + e[q].im * e[q].im);
+    }
     static_for<0, P>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       h[q] = mul_w<q, 2 * P, T>((xr[q] * w[q]) * rot);
@@ -134,32 +143,35 @@ __global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
 
     const unsigned t2 = 2u * tt;
     if constexpr (AMAX) {
-      T bv = T(-1);
 #pragma unroll
-      for (int q = 0; q < P; ++q)
-        bv = fmax(bv, fmax(e[q].re * e[q].re + e[q].im * e[q].im, h[q].re * h[q].re + h[q].im * h[q].im));
+      for (int q = 0; q < P; ++q) {
+        if constexpr (WRITE) bv = fmax(bv, e[q].re * e[q].re + e[q].im * e[q].im);
+        bv = fmax(bv, h[q].re * h[q].re + h[q].im * h[q].im);
+      }
       bv = amax_nan_if_unset(bv);
       amax_reduce_store<T, (int)NT>(bv, 0, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
     }
-    Cx<T>* __restrict__ orow = A.out + s * (long long)N;
-    typedef const T __attribute__((address_space(4))) * kptr_t;
-    kptr_t rc = (kptr_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
-                         __builtin_offsetof(PipeArgs<T>, ramp_c));
-    asm volatile("" : "+s"(rc));
-    static_for<0, P>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
-      const __amdgpu_buffer_rsrc_t rout = xm_rsrc(orow + base, 2u * NT * CB);
-      CxPair<T> o;
-      o.a = e[q];
-      o.b = h[q];
-      if constexpr (RAMP) {
-        const Cx<T> c = mk<T>(rc[2 * q], rc[2 * q + 1]);
-        o.a = o.a * c;
-        o.b = o.b * c;
-      }
-      buf_store(rout, t2 * CB, o);
-    });
+    if constexpr (WRITE) {
+      Cx<T>* __restrict__ orow = A.out + s * (long long)N;
+      typedef const T __attribute__((address_space(4))) * kptr_t;
+      kptr_t rc = (kptr_t)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                           __builtin_offsetof(PipeArgs<T>, ramp_c));
+      asm volatile("" : "+s"(rc));
+      static_for<0, P>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const unsigned base = (2u * NT * q + sh) & (N - 1u);  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rout = xm_rsrc(orow + base, 2u * NT * CB);
+        CxPair<T> o;
+        o.a = e[q];
+        o.b = h[q];
+        if constexpr (RAMP) {
+          const Cx<T> c = mk<T>(rc[2 * q], rc[2 * q + 1]);
+          o.a = o.a * c;
+          o.b = o.b * c;
+        }
+        buf_store(rout, t2 * CB, o);
+      });
+    }
   }
   wq.finish(t);
 }
