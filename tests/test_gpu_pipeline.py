@@ -323,3 +323,37 @@ def test_speculative_schedule_two_ranks_with_cross_rank_repair():
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "multi-rank speculative run_stream: OK" in r.stdout
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_speculative_stream_of_many_small_datasets_with_misses(mods, dtype):
+    """Fourteen small datasets in one call: the device period is far shorter than a search, so four searches are in
+    flight (`_search_workers`), the ring of guess / selection slots wraps twice, verifications lag two datasets and
+    three of the datasets are built to be guessed wrong (repaired, one of them the very first, one the last).  Every
+    (p0, p1, pivot, flat index) and every spectrum must equal the classic schedule's."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 96, 1024, 2048
+    t = np.arange(nt) * 2e-4
+    sets, wrong = [], {0, 6, 13}
+    for k in range(14):
+        x, _ = _three_peak(nv, nt, 2e-4, seed=900 + k)
+        x[(5 * k + 2) % nv] *= 2.0
+        if k in wrong:  # thirty well separated unit lines: largest L1 norm, not the tallest peak
+            x *= 0.05
+            x[7] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * (-2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)) * t) for j in range(30))
+            x[20 + k] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -400.0 * t)
+        sets.append(dev.to_device(x.astype(dtype)))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    assert pipe._search_workers(plan, nv, sets[0].element_size(), 8)[0] == 4
+    outs = [torch.empty((nv, target), dtype=sets[0].dtype, device="cuda") for _ in sets]
+    refs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, refs, plan)
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["repaired" if k in wrong else "hit" for k in range(14)]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert (a.flat_index, a.target_idx, a.pivot, a.p0, a.p1) == (b.flat_index, b.target_idx, b.pivot, b.p0, b.p1), k
+        tol = 2.5e-7 if dtype == "complex64" else 1e-14
+        assert float((outs[k] - refs[k]).abs().max()) <= tol * float(refs[k].abs().max()), k
