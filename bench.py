@@ -454,18 +454,20 @@ def footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms
         try:
             nv2 = nv // 2
             x2 = x[:nv2].to(torch.complex128)
-            out2 = torch.empty((nv2, N), dtype=torch.complex128, device=x.device)
+            # as the headline: outputs alternate between two buffers, the pipeline fill is inside the timed steps
+            out2 = [torch.empty((nv2, N), dtype=torch.complex128, device=x.device) for _ in range(2)]
             plan2 = pipeline.make_plan(x2, t, N, args.lb)
             trace = []
-            pipeline.run_stream([x2] * 4, [out2] * 4, plan2, speculate=speculate)
+            k2 = 40
+            pipeline.run_stream([x2] * 8, [out2[k % 2] for k in range(8)], plan2, speculate=speculate)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pipeline.run_stream([x2] * 16, [out2] * 16, plan2, speculate=speculate, trace=trace)
+            pipeline.run_stream([x2] * k2, [out2[k % 2] for k in range(k2)], plan2, speculate=speculate, trace=trace)
             torch.cuda.synchronize()
-            ms2 = (time.perf_counter() - t0) / 16 * 1e3
+            ms2 = (time.perf_counter() - t0) / k2 * 1e3
             main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
             bytes2 = 16 * (x2.shape[1] + N) * nv2
-            notes["c128"] = {"voxels": nv2, "value": nv2 / (ms2 * 1e-3), "ms_per_step": ms2, "main_kernel_ms": main2,
+            notes["c128"] = {"voxels": nv2, "steps": k2, "value": nv2 / (ms2 * 1e-3), "ms_per_step": ms2, "main_kernel_ms": main2,
                              "main_kernel_frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "end_to_end_roofline_frac": nv2 / (ms2 * 1e-3) * 16 * (x2.shape[1] + N) / 1e9 / HBM_PEAK_GBPS}
             del x2, out2
