@@ -399,6 +399,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # searches running ahead of the main pass being queued (= worker threads): two where the device period is longer
     # than a search, more -- with smaller teams, which use the cores better -- where the host would pace the steps
     workers, team = _search_workers(plan, nb, x0.element_size(), aps.default_threads())
+    if exchange is not None:
+        # several ranks: the look-ahead fixes the ORDER of the exchange calls, which every rank must make alike --
+        # it may not depend on anything a rank measures or owns (its shard size, its share of the host's cores)
+        workers = 2
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     ring = g_ahead + 2
