@@ -10,7 +10,8 @@
 //   * the 15 last-stage twiddles W_4096^{r t} of a thread are not held (60 VGPRs) but generated as a running product
 //     g, g^2, ... from g = W_4096^t (ChainTw: 15 extra complex multiplies per half, ~1e-15 relative);
 //   * the next row is not prefetched (its 64 VGPRs do not fit beside both halves; tried in front of the epilogue:
-//     190 spilled registers): the other workgroup computes while this one waits for its samples.
+//     190 spilled registers, and sample by sample between the epilogue's stores, each load taking the registers of
+//     the pair just stored: 230-350): the other workgroup computes while this one waits for its samples.
 // Measured (32,768 rows, MI355X): write + ramp 1.16 ms = 5.57 TB/s (k_zf2<double>: 1.31 with the ramp, 1.44 with
 // the table), with the per-row maxima 1.21 (1.43 / 1.60).  k_zf2p's conflict-free column remap was tried: LDS
 // conflicts 21 % -> 0 of the LDS cycles, time unchanged (the remapped 16-byte loads fill half a sector per
