@@ -209,3 +209,59 @@ def test_lazy_chain_is_fused_by_autophase(xm, oracle, monkeypatch, dtype):
     _same(two.xmr.autophase(), oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(o, lb=5.0)), peak_width=100), 1e-9)
     lg = a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum().xmr.autophase()
     _same(lg, oracle.autophase(oracle.to_spectrum(oracle.apodize_lg(o, lb=1.0, gb=2.0)), peak_width=100), 1e-9)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_lazy_chain_end_materialises_in_one_fused_launch(xm, oracle, monkeypatch, dtype):
+    """Asking the END of a recorded `to_spectrum(apodize_exp([zero_fill](fid)))` / `to_spectrum(zero_fill(fid))` chain
+    for its values (no autophase) runs ONE fused launch on the root -- none of the staged kernels, no intermediate --
+    and gives the oracle's spectrum, dims, coords, attrs and numpy's dtype; "symmetric" zero fills and N-D roots
+    included.  Chains the pattern does not cover (another window, the FID axis not last) run step by step."""
+    from xmris_amd import device as dev
+
+    rng = np.random.default_rng(31)
+    nt = 600
+    t = np.arange(nt) * 2.5e-4
+    x = (rng.standard_normal((3, 5, nt)) + 1j * rng.standard_normal((3, 5, nt))).astype(dtype)
+    a, o = _pair(xm, oracle, x, ("coil", "voxel", "time"), {"coil": np.arange(3), "voxel": np.arange(5), "time": t}, {"MHz": 120.0})
+    calls = {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 0}
+    for name in calls:
+        real = getattr(dev, name)
+        monkeypatch.setattr(dev, name, (lambda real, name: lambda *a_, **k_: (calls.__setitem__(name, calls[name] + 1), real(*a_, **k_))[1])(real, name))
+    tol = 1e-9 if dtype == "complex128" else 2e-5
+    for position in ("end", "symmetric"):
+        before = dict(calls)
+        sp = a.xmr.zero_fill(target_points=2048, position=position).xmr.apodize_exp(lb=3.0).xmr.to_spectrum()
+        assert sp.is_deferred and sp.dtype == np.complex128
+        ref = oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048, position=position), lb=3.0))
+        _same(sp, ref, 1e-9)  # .values: the chain end computes itself
+        assert not sp.is_deferred
+        assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 1}
+    # zero fill + spectrum without a window: the storage precision stays (no float64 operand in the chain)
+    before = dict(calls)
+    sp = a.xmr.zero_fill(target_points=1536).xmr.to_spectrum()
+    assert sp.dtype == np.dtype(dtype)
+    _same(sp, oracle.to_spectrum(oracle.zero_fill(o, target_points=1536)), tol)
+    assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 1}
+    # apodise + spectrum, no zero fill (a chirp-z length)
+    before = dict(calls)
+    _same(a.xmr.apodize_exp(lb=3.0).xmr.to_spectrum(), oracle.to_spectrum(oracle.apodize_exp(o, lb=3.0)), 1e-9)
+    assert calls["pipeline_fused"] - before["pipeline_fused"] == 1 and calls["fft"] == before["fft"]
+    # an intermediate that was looked at is real data: the rest of the chain (apodise + spectrum) fuses on IT
+    before = dict(calls)
+    zf = a.xmr.zero_fill(target_points=2048)
+    _ = zf.values
+    sp = zf.xmr.apodize_exp(lb=3.0).xmr.to_spectrum()
+    _same(sp, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=3.0)), 1e-9)
+    assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 1, "apodize": 0, "fft": 0, "pipeline_fused": 1}
+    # ... and a chain the pattern does not cover (apodize_lg) runs its steps one by one
+    before = dict(calls)
+    _same(a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum(), oracle.to_spectrum(oracle.apodize_lg(o, lb=1.0, gb=2.0)), 1e-9)
+    assert calls["apodize"] - before["apodize"] == 1 and calls["fft"] - before["fft"] == 1
+    # the FID axis is not the last one: staged (the host moves axes there)
+    xt = np.ascontiguousarray(x[0].T)
+    b, ob = _pair(xm, oracle, xt, ("time", "voxel"), {"time": t, "voxel": np.arange(5)}, {})
+    before = dict(calls)
+    sp = b.xmr.zero_fill(target_points=1024).xmr.apodize_exp(lb=3.0).xmr.to_spectrum()
+    _same(sp, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(ob, target_points=1024), lb=3.0)), 1e-9)
+    assert calls["pipeline_fused"] == before["pipeline_fused"] and calls["fft"] - before["fft"] == 1

@@ -49,6 +49,11 @@ def _is_tensor(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda")
 
 
+# set by xmris_amd.processing: a function that recognises a whole recorded chain when its END is asked for its data and
+# computes it in one fused launch (returns None for anything else: the steps then run one by one)
+_materialise_hook = None
+
+
 class Deferred:
     """Array data that has not been computed yet (the lazy accessor chain): `thunk()` produces
     it on first use, `shape` / `dtype` are known up front (all metadata of the hot path is host arithmetic on
@@ -91,7 +96,8 @@ class LabeledArray:
     @property
     def data(self):
         if self._data is None:
-            self._data = self._lazy.thunk()
+            fused = _materialise_hook(self) if _materialise_hook is not None else None
+            self._data = fused if fused is not None else self._lazy.thunk()
             self._lazy = None  # the recorded chain (and its references to the parents) is no longer needed
         return self._data
 

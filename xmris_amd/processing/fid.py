@@ -61,7 +61,8 @@ def apodize_exp(da, dim: str = DIMS.time, lb: float = 1.0):
     src = as_labeled(da)
     _check_dims(src, dim, "apodize_exp")
     t = src.coords[dim].values  # KeyError when `dim` has no coordinate, like the reference
-    out = _apodize(src, dim, np.exp(-np.pi * lb * t), step=("apodize_exp", {"dim": dim, "lb": lb}))
+    w = np.exp(-np.pi * lb * t)
+    out = _apodize(src, dim, w, step=("apodize_exp", {"dim": dim, "lb": lb, "_weight": w}))
     out.attrs[ATTRS.apodization_lb] = lb
     return like_input(out, da)
 
