@@ -1,4 +1,4 @@
-"""BASELINE.json configs[1] and configs[4] at their literal N-D shapes through the drop-in surface:
+"""BASELINE.json configs[1], configs[2] (full size) and configs[4] at their literal shapes through the drop-in surface:
   C2  (32, 32, 16, 2048)  3-D MRSI grid, zero-filled to 4096 (and the literal no-op target_points=2048)
   C5  (8, 64, 64, 1536)   multi-coil, non-power-of-two length (2^9 * 3), no zero fill, both storage precisions
 Each goes through the chained `.xmr` calls AND `.xmr.spectral_pipeline`; the oracle runs on 64 sampled voxels plus the
@@ -120,3 +120,57 @@ def test_c2_shape_with_the_fid_axis_first(oracle):
     assert np.abs(g - oc.values).max() <= 1e-9 * np.abs(oc.values).max()
     fused = a.xmr.spectral_pipeline(target_points=target, lb=lb)  # falls back to the staged calls for this layout
     assert fused.dims == got.dims and np.abs(fused.values - got.values).max() <= 1e-9 * np.abs(got.values).max()
+
+
+@pytest.mark.parametrize("dtype,nv", [("complex64", 65536), ("complex128", 32768)])
+def test_c3_roofline_config_65536x4096_full_size(oracle, dtype, nv):
+    """BASELINE configs[2] at its full size (65,536 voxels x 4096 -> 8192, complex64, the bench's synthetic data
+    generated on the device; and the bench's complex128 sub-record: 32,768 voxels): both schedules of the streaming executor and the accessor's fused pipeline.  The oracle
+    runs on the first 64, the last 64 and the voxels around the designated brightest one (which fixes the global
+    arg-max, hence (p0, p1), for the subset as for the whole array); every voxel is checked through size-independent
+    properties on the device: Parseval against the apodised FID, the arg-max voxel, speculative == classic."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import xmris_amd as xm
+    from xmris_amd import pipeline
+
+    nt, n_out, lb = 4096, 8192, 5.0
+    cdt = getattr(torch, dtype)
+    tol = 1e-5 if dtype == "complex64" else 1e-10
+    x, t = bench.synth_fids(torch, nv, nt, 1.0 / 5000.0, 0, nv, torch.device("cuda"), cdt)
+    star = nv // 3
+    plan = pipeline.make_plan(x, t, n_out, lb)
+    outs = [torch.empty((nv, n_out), dtype=cdt, device="cuda") for _ in range(2)]
+    classic = pipeline.run_stream([x], [outs[0]], plan)[0]
+    spec = pipeline.run_stream([x], [outs[1]], plan, speculate=True)[0]
+    torch.cuda.synchronize()
+    assert spec.speculation == "hit" and classic.flat_index // n_out == star == spec.flat_index // n_out
+    assert (classic.p0, classic.p1, classic.pivot, classic.flat_index) == (spec.p0, spec.p1, spec.pivot, spec.flat_index)
+    scale = float(outs[0].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= (2.5e-7 if dtype == "complex64" else 1e-14) * scale  # contraction only
+    # every voxel: Parseval (ortho FFT, unit-modulus phase) and the global maximum
+    w = torch.from_numpy(np.exp(-np.pi * lb * t)).to("cuda", torch.float64)
+    e_fid = ((x.to(torch.complex128) * w).abs() ** 2).sum(dim=1)
+    for o in outs:
+        e_spec = (o.to(torch.complex128).abs() ** 2).sum(dim=1)
+        assert float(((e_spec - e_fid).abs() / e_fid).max()) < (2e-5 if dtype == "complex64" else 1e-12)
+        assert int(torch.argmax(o.abs().reshape(-1))) // n_out == star
+    # the oracle on a subset that contains the brightest voxel
+    sub = np.unique(np.concatenate([np.arange(64), np.arange(nv - 64, nv), np.arange(star - 2, star + 3)]))
+    xs = x[torch.from_numpy(sub).cuda()].cpu().numpy()
+    ref, info = oracle.pipeline_values(xs.astype(np.complex128), t, n_out, lb, peak_width=100)
+    assert info["pivot"] == classic.pivot and abs(info["p0"] - classic.p0) < 1e-6 and abs(info["p1"] - classic.p1) < 1e-6
+    got = outs[1][torch.from_numpy(sub).cuda()].cpu().numpy()
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # the accessor's fused pipeline on the device-resident array
+    del outs
+    a = xm.LabeledArray(x, ("voxel", "time"), {"time": t}, {})
+    fused = a.xmr.spectral_pipeline(target_points=n_out, lb=lb)
+    assert abs(fused.attrs["phase_p0"] - info["p0"]) < 1e-6 and abs(fused.attrs["phase_p1"] - info["p1"]) < 1e-6
+    g = fused.data[torch.from_numpy(sub).cuda()].cpu().numpy()
+    assert np.abs(g - ref).max() <= tol * np.abs(ref).max()
