@@ -115,6 +115,31 @@ def default_threads() -> int:
     return team
 
 
+def burst_threads() -> int:
+    """Team size for ONE search with nothing beside it (a single accessor call: the device waits for it, no other
+    search runs): the whole share of the CPUs this process may use, up to 16 -- `default_threads` keeps half of it
+    free because a streaming executor's teams spin for as long as it runs; a millisecond does not reach the quota."""
+    import os
+
+    if os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
+        return default_threads()
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    team = 1
+    while team * 2 <= min(16, cpus):
+        team *= 2
+    return max(team, default_threads())
+
+
 class NativeObjective:
     """The three objectives evaluated by libxmris_hip.so's host solver (vectorised C++, fp64)."""
 

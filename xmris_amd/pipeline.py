@@ -143,7 +143,7 @@ class Selection:
 
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
                      p0_only=False, exchange=None, rank_offset_rows=0, disp=False, on_host_phase=None,
-                     selection: "Selection | None" = None):
+                     selection: "Selection | None" = None, threads=None):
     """phasing.py:226-287 on the outputs of the pre-pass.  `exchange(max_abs, flat)` may merge the
     per-rank winners (returns (owner_is_me, global_flat)); default = single device.
     `on_host_phase()` is called once the device has nothing left to do for this dataset until the
@@ -184,7 +184,8 @@ def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", pea
         if on_host_phase is not None:
             on_host_phase()
         iw = aps.index_width_of(plan.freq, peak_width)
-        p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp)
+        p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp,
+                                threads=threads)
         res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
         res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
     elif on_host_phase is not None:
@@ -210,7 +211,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     if params is None:  # arg-max reduction, row gather, fp64 slice and D2H all queued without host syncs
         sel = Selection(x2, plan, pre.absmax2, pre.argidx, index_from_slice=True)
         res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only,
-                                  selection=sel)
+                                  selection=sel, threads=aps.burst_threads())  # one search, nothing beside it
     else:
         res = _selection_only(pre, plan, target_coord)
     if params is not None:
@@ -467,7 +468,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                            key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
 
     full_team = aps.default_threads()
-    fill_team = full_team  # (a larger one-off team for the pipeline-filling search bought nothing measurable)
+    # (a larger one-off team for the pipeline-filling search bought nothing measurable: the next searches start beside
+    # it; a single dataset has the host to itself)
+    fill_team = aps.burst_threads() if n_sets == 1 else full_team
 
     def search(sl, k, pivot, threads):
         return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads)

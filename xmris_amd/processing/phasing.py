@@ -138,5 +138,5 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
     if method not in aps.METHODS:
         raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
     p0_opt, p1_opt, _ = aps.solve(work, work_coords, pivot, target_idx, index_width, method=method,
-                                  p0_only=p0_only, disp=kwargs.get("disp"))
+                                  p0_only=p0_only, disp=kwargs.get("disp"), threads=aps.burst_threads())
     return like_input(_phase_labeled(src, x, dim, p0_opt, p1_opt, pivot), da)  # phasing.py:290
