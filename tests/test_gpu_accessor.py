@@ -254,10 +254,16 @@ def test_lazy_chain_end_materialises_in_one_fused_launch(xm, oracle, monkeypatch
     sp = zf.xmr.apodize_exp(lb=3.0).xmr.to_spectrum()
     _same(sp, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=3.0)), 1e-9)
     assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 1, "apodize": 0, "fft": 0, "pipeline_fused": 1}
-    # ... and a chain the pattern does not cover (apodize_lg) runs its steps one by one
+    # the Lorentz-to-Gauss window fuses like the exponential one
     before = dict(calls)
-    _same(a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum(), oracle.to_spectrum(oracle.apodize_lg(o, lb=1.0, gb=2.0)), 1e-9)
-    assert calls["apodize"] - before["apodize"] == 1 and calls["fft"] - before["fft"] == 1
+    _same(a.xmr.zero_fill(target_points=2048).xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum(),
+          oracle.to_spectrum(oracle.apodize_lg(oracle.zero_fill(o, target_points=2048), lb=1.0, gb=2.0)), 1e-9)
+    assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 1}
+    # ... and a chain the pattern does not cover (two windows) runs its steps one by one
+    before = dict(calls)
+    _same(a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.apodize_exp(lb=2.0).xmr.to_spectrum(),
+          oracle.to_spectrum(oracle.apodize_exp(oracle.apodize_lg(o, lb=1.0, gb=2.0), lb=2.0)), 1e-9)
+    assert calls["apodize"] - before["apodize"] == 2 and calls["fft"] - before["fft"] == 1
     # the FID axis is not the last one: staged (the host moves axes there)
     xt = np.ascontiguousarray(x[0].T)
     b, ob = _pair(xm, oracle, xt, ("time", "voxel"), {"time": t, "voxel": np.arange(5)}, {})

@@ -83,7 +83,7 @@ def binary_op_name(da: LabeledArray, dim: str):
 
 
 def fused_materialise(la: LabeledArray):
-    """The data of `to_spectrum(apodize_exp([zero_fill](fid)))` / `to_spectrum(zero_fill(fid))` when the whole chain is
+    """The data of `to_spectrum(apodize_exp | apodize_lg([zero_fill](fid)))` / `to_spectrum(zero_fill(fid))` when the whole chain is
     still recorded and its END is asked for: ONE launch of the fused kernel (zero fill + window + ortho FFT +
     fftshift, `xm_pipeline_fused`) on the root instead of three staged passes with two intermediates (22 GiB of
     traffic instead of 6 for 32,768 x 4096 -> 8192 complex128).  None when the pattern does not apply -- another chain,
@@ -93,10 +93,11 @@ def fused_materialise(la: LabeledArray):
         nodes.append(node._lazy.step)
         node = node._lazy.parent
     root = node
-    names = [s_[0] for s_ in nodes]
-    if names not in (["to_spectrum", "apodize_exp", "zero_fill"], ["to_spectrum", "apodize_exp"], ["to_spectrum", "zero_fill"]):
+    # either window (the kernel takes the weights as they are)
+    names = ["apodize" if s_[0] in ("apodize_exp", "apodize_lg") else s_[0] for s_ in nodes]
+    if names not in (["to_spectrum", "apodize", "zero_fill"], ["to_spectrum", "apodize"], ["to_spectrum", "zero_fill"]):
         return None
-    steps = {s_[0]: s_[1] for s_ in nodes}
+    steps = {name: s_[1] for name, s_ in zip(names, nodes)}
     d0 = steps["to_spectrum"]["dim"]
     if any(steps[k]["dim"] != d0 for k in steps) or d0 not in root.dims or root.get_axis_num(d0) != root.ndim - 1:
         return None
@@ -113,10 +114,10 @@ def fused_materialise(la: LabeledArray):
         n_out = int(steps["zero_fill"]["target_points"])
         pad_left = (n_out - n) // 2 if steps["zero_fill"]["position"] == "symmetric" else 0
     window = None
-    if "apodize_exp" in steps:
+    if "apodize" in steps:
         x = promote_for_float64_operand(x)  # complex64 * float64 window -> complex128 (fid.py:136-139)
         rd = torch.float64 if x.dtype == torch.complex128 else torch.float32
-        window = torch.from_numpy(np.ascontiguousarray(steps["apodize_exp"]["_weight"], dtype=np.float64)).to(x.device, rd)
+        window = torch.from_numpy(np.ascontiguousarray(steps["apodize"]["_weight"], dtype=np.float64)).to(x.device, rd)
     if x.numel() == 0 or not dev.fft_supported(n_out, complex128=x.dtype == torch.complex128):
         return None  # the staged steps raise the reference's own errors
     x2 = x.reshape(-1, n)

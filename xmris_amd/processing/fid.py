@@ -76,7 +76,7 @@ def apodize_lg(da, dim: str = DIMS.time, lb: float = 1.0, gb: float = 1.0):
     if gb != 0:
         t_g = (2 * np.sqrt(np.log(2))) / (np.pi * gb)
         w = w * np.exp(-(t**2) / (t_g**2))
-    out = _apodize(src, dim, w)
+    out = _apodize(src, dim, w, step=("apodize_lg", {"dim": dim, "lb": lb, "gb": gb, "_weight": w}))
     out.attrs[ATTRS.apodization_lb] = lb
     out.attrs[ATTRS.apodization_gb] = gb
     return like_input(out, da)
