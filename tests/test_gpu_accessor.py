@@ -203,12 +203,17 @@ def test_lazy_chain_is_fused_by_autophase(xm, oracle, monkeypatch, dtype):
     _same(sp2, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=5.0)), 1e-9)  # .values
     assert not sp2.is_deferred
     _same(sp2.xmr.autophase(), oc, 1e-9)
-    # without a zero fill, and a chain the pattern does not cover (apodize_lg): staged
+    # without a zero fill, and with the Lorentz-to-Gauss window (its weights and lineage attrs travel with the step)
     two = a.xmr.apodize_exp(lb=5.0).xmr.to_spectrum()
     assert two.is_deferred
     _same(two.xmr.autophase(), oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(o, lb=5.0)), peak_width=100), 1e-9)
+    before = dict(calls)
     lg = a.xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum().xmr.autophase()
     _same(lg, oracle.autophase(oracle.to_spectrum(oracle.apodize_lg(o, lb=1.0, gb=2.0)), peak_width=100), 1e-9)
+    lg = a.xmr.zero_fill(target_points=2048).xmr.apodize_lg(lb=1.0, gb=2.0).xmr.to_spectrum().xmr.autophase()
+    _same(lg, oracle.autophase(oracle.to_spectrum(oracle.apodize_lg(oracle.zero_fill(o, target_points=2048), lb=1.0, gb=2.0)),
+                               peak_width=100), 1e-9)
+    assert calls == before  # fused, both times
 
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])

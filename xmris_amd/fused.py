@@ -19,7 +19,10 @@ from .dims import _check_dims, term_attrs
 
 def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,
                       out_dim: str = DIMS.frequency, position: str = "end", method: str = "acme",
-                      peak_width=100, target_coord=None, p0_only: bool = False, mode: str = "single", **kwargs):
+                      peak_width=100, target_coord=None, p0_only: bool = False, mode: str = "single", _window=None,
+                      _apodization_attrs=None, **kwargs):
+    """`_window` / `_apodization_attrs` (private: the lazy chain's `apodize_lg`): the weights over the zero-filled axis
+    and the lineage attrs that replace `apodization_lb = lb`."""
     src = as_labeled(da)
     _check_dims(src, dim, "zero_fill")
     if position not in ("end", "symmetric"):
@@ -41,7 +44,7 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     x2 = xm.reshape(-1, xm.shape[-1])
     if not x2.is_contiguous():
         x2 = x2.contiguous()
-    plan = pl.make_plan(x2, t, target_points, lb, position)
+    plan = pl.make_plan(x2, t, target_points, lb, position, window_host=_window)
     if ax != nd - 1:
         # the global arg-max must follow the ORIGINAL C order (phasing.py:229); with the FID axis moved
         # the fused pre-pass would break ties differently, so fall back to the staged calls
@@ -71,7 +74,10 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     if target_points > n:
         attrs[ATTRS.zero_fill_target] = target_points
         attrs[ATTRS.zero_fill_position] = position
-    attrs[ATTRS.apodization_lb] = lb
+    if _apodization_attrs is not None:
+        attrs.update(_apodization_attrs)
+    else:
+        attrs[ATTRS.apodization_lb] = lb
     attrs[ATTRS.phase_p0] = res.p0
     attrs[ATTRS.phase_p1] = res.p1
     attrs[ATTRS.phase_pivot] = res.pivot

@@ -46,7 +46,8 @@ def zero_fill_coords(t: np.ndarray, target_points: int, pad_left: int) -> np.nda
     return (t[0] - (pad_left * delta)) + np.arange(target_points) * delta
 
 
-def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end") -> PipelinePlan:
+def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end", window_host=None) -> PipelinePlan:
+    """`window_host`: the apodisation weights over the zero-filled axis when they are not exp(-pi lb t) (`apodize_lg`)."""
     import torch
 
     n_in = x2.shape[-1]
@@ -63,6 +64,10 @@ def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end") 
             raise ValueError("`position` must be either 'end' or 'symmetric'.")
         tt = zero_fill_coords(t, n_out, pad_left) if len(t) > 1 else t
     win = np.exp(-np.pi * lb * tt) if lb is not None else np.ones(n_out)
+    if window_host is not None:
+        win = np.asarray(window_host, dtype=np.float64)
+        if win.shape != (n_out,):
+            raise ValueError("window_host must cover the zero-filled axis")
     delta = (tt[1] - tt[0]) if len(tt) > 1 else 1.0
     freq = np.roll(np.fft.fftfreq(n_out, d=delta), n_out // 2)
     rd = torch.float32 if x2.dtype == torch.complex64 else torch.float64

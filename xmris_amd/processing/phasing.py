@@ -69,10 +69,11 @@ def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_on
     if not src.is_deferred or lb > 0:
         return None
     steps, root = src.pending_chain()
-    names = [s_[0] for s_ in steps]
-    if names not in (["to_spectrum", "apodize_exp", "zero_fill"], ["to_spectrum", "apodize_exp"]):
+    names = ["apodize" if s_[0] in ("apodize_exp", "apodize_lg") else s_[0] for s_ in steps]
+    if names not in (["to_spectrum", "apodize", "zero_fill"], ["to_spectrum", "apodize"]):
         return None
     sp, ap = steps[0][1], steps[1][1]
+    lg = steps[1][0] == "apodize_lg"
     zf = steps[2][1] if len(steps) == 3 else None
     d0 = sp["dim"]
     if sp["out_dim"] != dim or ap["dim"] != d0 or (zf is not None and zf["dim"] != d0):
@@ -86,9 +87,14 @@ def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_on
     x, _ = device_data(root)
     base = root.copy(data=promote_for_float64_operand(x))  # the staged chain is complex128 from apodize_exp on
     n = root.sizes[d0]
+    extra = {}
+    if lg:  # the Lorentz-to-Gauss weights as recorded, and the lineage attrs that call stamps (fid.py:190-196)
+        from ..config import ATTRS
+
+        extra = dict(_window=ap["_weight"], _apodization_attrs={ATTRS.apodization_lb: ap["lb"], ATTRS.apodization_gb: ap["gb"]})
     return spectral_pipeline(base, target_points=zf["target_points"] if zf is not None else n, lb=ap["lb"], dim=d0,
                              out_dim=dim, position=zf["position"] if zf is not None else "end", method=method,
-                             peak_width=peak_width, target_coord=target_coord, p0_only=p0_only)
+                             peak_width=peak_width, target_coord=target_coord, p0_only=p0_only, **extra)
 
 
 def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "single",
