@@ -26,3 +26,4 @@ run("C3 65536 x 4096 -> 8192", 65536, 4096, 8192)
 run("C5 32768 x 1536", 32768, 1536, 1536)
 run("prime 32768 x 1531 (Bluestein)", 32768, 1531, 1531)
 run("65536 x 4096 (no zero fill)", 65536, 4096, 4096)
+run("32768 x 8192 -> 16384", 32768, 8192, 16384)

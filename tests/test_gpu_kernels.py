@@ -491,10 +491,12 @@ def test_phase_ramp_equals_phase_table(dev):
 
     for dtype, n_in, n_out, pad in (("complex64", 4096, 8192, 0), ("complex64", 2048, 4096, 0), ("complex64", 1000, 2048, 0),
                                     ("complex64", 400, 1024, 0), ("complex64", 1001, 2048, 0), ("complex64", 1536, 1536, 0),
-                                    ("complex64", 1000, 4096, 24), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0),
+                                    ("complex64", 1000, 4096, 24), ("complex64", 8192, 16384, 0), ("complex64", 5000, 16384, 100),
+                                    ("complex64", 5001, 16384, 0), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0),
                                     ("complex128", 2048, 4096, 0), ("complex128", 1001, 2048, 3), ("complex128", 400, 1024, 0),
                                     ("complex128", 3000, 8192, 24), ("complex128", 2049, 4096, 0)):
-        nb = 2100 if (dtype == "complex128" and n_out <= 4096) else 37  # more rows than the persistent grid's first round
+        # more rows than the persistent grid's first round
+        nb = 2100 if (dtype == "complex128" and n_out <= 4096) else (600 if n_out == 16384 else 37)
         x = dev.to_device(_rand((nb, n_in), dtype, seed=n_in + n_out))
         rd = torch.float32 if dtype == "complex64" else torch.float64
         w = torch.linspace(1.0, 0.1, n_out, device="cuda", dtype=rd)
@@ -503,7 +505,7 @@ def test_phase_ramp_equals_phase_table(dev):
         ref = dev.pipeline_fused(x, n_out, pad, window=w, phase_table=table).out.cpu().numpy()
         got = dev.pipeline_fused(x, n_out, pad, window=w, phase_ramp=(a, b)).out.cpu().numpy()
         native = dev.ramp_native(x, n_out, pad)
-        zf2 = 2 * (pad + n_in) <= n_out and n_out in (1024, 2048, 4096, 8192)
+        zf2 = 2 * (pad + n_in) <= n_out and (n_out in (1024, 2048, 4096, 8192) or (n_out == 16384 and dtype == "complex64"))
         assert native == (zf2 and (dtype == "complex128" or (n_in % 2 == 0 and pad % 2 == 0))), (dtype, n_in, n_out, pad)
         assert _relerr(got, ref) < (1e-6 if dtype == "complex64" else 1e-13), (dtype, n_in, n_out, pad, native)
 
@@ -578,7 +580,7 @@ def test_randomised_geometries_of_the_fused_entry_point(dev, oracle):
     import torch
 
     rng = np.random.default_rng(20240611)
-    lengths = [64, 128, 512, 1024, 2048, 4096, 8192, 384, 768, 1536, 3072, 5120, 1000, 1531, 2000]
+    lengths = [64, 128, 512, 1024, 2048, 4096, 8192, 16384, 384, 768, 1536, 3072, 5120, 1000, 1531, 2000]
     batches = [1, 2, 3, 17, 255, 512, 513, 1025, 2100]
     for case in range(120):
         dtype = "complex64" if rng.random() < 0.5 else "complex128"

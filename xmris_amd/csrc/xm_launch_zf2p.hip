@@ -23,7 +23,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   if (A.n_batch <= 0) return XM_OK;
   constexpr bool L16 = (OPT & ZF2P_LOAD16) != 0;
   using FFT = BlockFFT<xm_f2, PL, L16 ? xm_ilog2(2 * PL::radix(0)) : -1>;
-  const size_t lds = (size_t)FFT::lds_elems() * sizeof(Cx<xm_f2>) + (size_t)HotTw<T, PL>::mid_size() * sizeof(Cx<T>) +
+  const size_t lds = (size_t)FFT::lds_elems() * sizeof(Cx<xm_f2>) + (size_t)HotTw<T, PL>::mid_lds_size() * sizeof(Cx<T>) +
                      ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
   static XmResidency res;
   int resident = 0;
@@ -98,6 +98,7 @@ int xm_zf2p_launch(int h, const PipeArgs<float>& A, const double* ramp, hipStrea
     case 1024: return launch_plan<typename Zf2PlanOf<1024>::type>(A, ramp, st);
     case 2048: return launch_plan<typename Zf2PlanOf<2048>::type>(A, ramp, st);
     case 4096: return launch_plan<typename PlanOf<4096>::type>(A, ramp, st);  // 256 threads x 16 points, 16.16.16
+    case 8192: return launch_plan<typename Zf2PlanOf<8192>::type>(A, ramp, st);  // 1024 x 8, one workgroup per CU
     default: break;
   }
   return xm_fail(XM_ERR_UNSUPPORTED_N, "no half-length plan for " + std::to_string(h));

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
   Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
-  T* red_v = reinterpret_cast<T*>(mid + HT::mid_size());
+  T* red_v = reinterpret_cast<T*>(mid + HT::mid_lds_size());  // half length 8192: the 32 KB of middle twiddles stay in L2
   int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
   unsigned* lds_next = reinterpret_cast<unsigned*>(red_i + NT / XM_WAVE + 1);
   constexpr bool QUEUE = (OPT & ZF2P_QUEUE) != 0;
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   const unsigned col = L16 ? (t & ~(XM_WAVE - 1u)) + 2u * (lane & 31u) + half : t;
 
   HT tw;
-  tw.mid = mid;
+  tw.mid = HT::mid_in_lds() ? mid : A.tw;
   tw.load(A.tw, (int)t);
-  for (unsigned i = t; i < (unsigned)HT::mid_size(); i += NT) mid[i] = A.tw[i];
+  for (unsigned i = t; i < (unsigned)HT::mid_lds_size(); i += NT) mid[i] = A.tw[i];
   if constexpr (RAMP) {  // per-thread part of the output phase, e^{i b 2t}, folded into the last-stage twiddles
     double sn, cs;
     sincos(A.ramp_db * (double)(2u * t), &sn, &cs);
