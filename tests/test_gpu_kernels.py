@@ -210,9 +210,9 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     assert abs(amax - np.abs(spec).max()) < 1e-5 * np.abs(spec).max()
     np.testing.assert_array_equal(pre.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1))
     # (1b) value-only pre-pass (the bench's mode): same per-spectrum maxima, bit for bit -- except on the complex128
-    # hot shape, where the value-only modes run another kernel (k_zf2d: 16-point butterflies) than the index modes
+    # shapes of k_zf2d (-> 8192, -> 16384), which takes the value-only modes only: another kernel than the index modes'
     vo = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True, argmax_value_only=True)
-    if dtype == "complex128" and (n_out, pad_left) == (8192, 0) and 2 * n_in <= n_out:
+    if dtype == "complex128" and n_out in (8192, 16384) and pad_left == 0 and 2 * n_in <= n_out:
         assert torch.allclose(vo.absmax2, pre.absmax2, rtol=1e-13, atol=0.0)
     else:
         assert torch.equal(vo.absmax2, pre.absmax2)
@@ -494,7 +494,7 @@ def test_phase_ramp_equals_phase_table(dev):
                                     ("complex64", 1000, 4096, 24), ("complex64", 8192, 16384, 0), ("complex64", 5000, 16384, 100),
                                     ("complex64", 5001, 16384, 0), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0),
                                     ("complex128", 2048, 4096, 0), ("complex128", 1001, 2048, 3), ("complex128", 400, 1024, 0),
-                                    ("complex128", 3000, 8192, 24), ("complex128", 2049, 4096, 0)):
+                                    ("complex128", 3000, 8192, 24), ("complex128", 2049, 4096, 0), ("complex128", 8192, 16384, 0)):
         # more rows than the persistent grid's first round
         nb = 2100 if (dtype == "complex128" and n_out <= 4096) else (600 if n_out == 16384 else 37)
         x = dev.to_device(_rand((nb, n_in), dtype, seed=n_in + n_out))
@@ -505,20 +505,21 @@ def test_phase_ramp_equals_phase_table(dev):
         ref = dev.pipeline_fused(x, n_out, pad, window=w, phase_table=table).out.cpu().numpy()
         got = dev.pipeline_fused(x, n_out, pad, window=w, phase_ramp=(a, b)).out.cpu().numpy()
         native = dev.ramp_native(x, n_out, pad)
-        zf2 = 2 * (pad + n_in) <= n_out and (n_out in (1024, 2048, 4096, 8192) or (n_out == 16384 and dtype == "complex64"))
+        zf2 = 2 * (pad + n_in) <= n_out and n_out in (1024, 2048, 4096, 8192, 16384)
         assert native == (zf2 and (dtype == "complex128" or (n_in % 2 == 0 and pad % 2 == 0))), (dtype, n_in, n_out, pad)
         assert _relerr(got, ref) < (1e-6 if dtype == "complex64" else 1e-13), (dtype, n_in, n_out, pad, native)
 
 
-@pytest.mark.parametrize("n_in,pad", [(4096, 0), (3000, 7), (4095, 1), (1, 0)])
-def test_complex128_hot_kernel_modes(dev, oracle, n_in, pad):
+@pytest.mark.parametrize("n_in,pad,n_out", [(4096, 0, 8192), (3000, 7, 8192), (4095, 1, 8192), (1, 0, 8192), (8192, 0, 16384),
+                                            (5000, 3, 16384)])
+def test_complex128_hot_kernel_modes(dev, oracle, n_in, pad, n_out):
     """k_zf2d (complex128, -> 8192: two workgroups per CU, halves one after the other, generated last-stage
-    twiddles) in each of its modes -- plain, ramp, ramp + per-row maxima, maxima without ramp -- against numpy in
+    twiddles; -> 16384: one 1024-thread workgroup per CU, register twiddles) in each of its modes -- plain, ramp, ramp + per-row maxima, maxima without ramp -- against numpy in
     fp64, on more rows than one round of the persistent grid (the row queue hands out the rest), ragged / shifted
     zero fills and a row of NaNs."""
     import torch
 
-    nb, n_out = 1100, 8192
+    nb = 1100 if n_out == 8192 else 600  # (half length 8192: one 1024-thread workgroup per CU, 256 in the first round)
     x = _rand((nb, n_in), "complex128", seed=n_in + pad)
     x[5] *= 3.0
     x[17, 0] = np.nan

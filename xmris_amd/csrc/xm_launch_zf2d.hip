@@ -11,17 +11,16 @@
 namespace {
 
 using T = double;
-using PL = typename PlanOf<4096>::type;  // 256 threads x 16 points, radices 16.16.16
 
-template <int MODE>
+template <class PL, int MODE>
 int launch_mode(PipeArgs<T> A, hipStream_t st) {
   const void* tw = nullptr;
   int rc = xm_table_get(TK_TWIDDLE, PL::N, PL::NT, XM_C128, xm_gen_twiddles<PL>, nullptr, &tw);
   if (rc) return rc;
   A.tw = (const Cx<T>*)tw;
   if (A.n_batch <= 0) return XM_OK;
-  const size_t lds = (size_t)BlockFFT<T, PL>::lds_elems() * sizeof(Cx<T>) +
-                     (size_t)ChainTw<T, PL, false>::mid_size() * sizeof(Cx<T>) +
+  constexpr size_t mid_bytes = (size_t)PL::tw_offset(PL::K - 1) * sizeof(Cx<T>);  // must mirror k_zf2d
+  const size_t lds = (size_t)BlockFFT<T, PL>::lds_elems() * sizeof(Cx<T>) + (mid_bytes <= 8192 ? mid_bytes : 0) +
                      ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
   static XmResidency res;
   int resident = 0;
@@ -37,15 +36,10 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   return XM_OK;
 }
 
-}  // namespace
-
-int xm_zf2d_launch(const PipeArgs<double>& A_in, const double* ramp, hipStream_t st, bool* handled) {
-  static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // tuning switch: k_zf2<double>
-  PipeArgs<double> A = A_in;
-  const bool wr = A.out != nullptr, ph = A.phase != nullptr, am = A.absmax2 != nullptr;
-  *handled = !gen1 && !ph && (wr ? (!am || A.amax_value_only) : (am && A.amax_value_only));
-  if (!*handled) return XM_OK;
-  if (!wr) return launch_mode<ZF2_AMAX | ZF2_VALUE_ONLY>(A, st);
+template <class PL>
+int launch_plan(PipeArgs<double> A, const double* ramp, hipStream_t st) {
+  const bool wr = A.out != nullptr, am = A.absmax2 != nullptr;
+  if (!wr) return launch_mode<PL, ZF2_AMAX | ZF2_VALUE_ONLY>(A, st);
   if (ramp) {
     // e^{i (a + b k)}, k = base_q + 2t (+1): the wave-uniform factors, and e^{i b} for the odd bins (xm_zf2p.h)
     constexpr unsigned N = 2 * PL::N;
@@ -58,7 +52,18 @@ int xm_zf2d_launch(const PipeArgs<double>& A_in, const double* ramp, hipStream_t
     A.ramp_e[0] = std::cos(ramp[1]);
     A.ramp_e[1] = std::sin(ramp[1]);
     A.ramp_db = ramp[1];
-    return am ? launch_mode<ZF2_WRITE | ZF2_RAMP | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<ZF2_WRITE | ZF2_RAMP>(A, st);
+    return am ? launch_mode<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<PL, ZF2_WRITE | ZF2_RAMP>(A, st);
   }
-  return am ? launch_mode<ZF2_WRITE | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<ZF2_WRITE>(A, st);
+  return am ? launch_mode<PL, ZF2_WRITE | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<PL, ZF2_WRITE>(A, st);
+}
+
+}  // namespace
+
+int xm_zf2d_launch(int h, const PipeArgs<double>& A, const double* ramp, hipStream_t st, bool* handled) {
+  static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // tuning switch: k_zf2<double> / the long-transform path
+  const bool wr = A.out != nullptr, ph = A.phase != nullptr, am = A.absmax2 != nullptr;
+  *handled = !gen1 && !ph && (wr ? (!am || A.amax_value_only) : (am && A.amax_value_only)) && (h == 4096 || h == 8192);
+  if (!*handled) return XM_OK;
+  if (h == 4096) return launch_plan<typename PlanOf<4096>::type>(A, ramp, st);  // 256 threads x 16 points, 16.16.16
+  return launch_plan<typename Zf2PlanOf<8192>::type>(A, ramp, st);               // 1024 threads x 8 points, 8.8.8.8.2
 }

@@ -1,4 +1,6 @@
-// k_zf2d -- the complex128 twin of k_zf2p for the hot shape (4096 -> 8192, ">= 2x end zero fill").
+// k_zf2d -- the complex128 twin of k_zf2p for the hot shape (4096 -> 8192, ">= 2x end zero fill"); with the 1024-thread
+// plan of the half length 8192 (one workgroup per CU, RotTw below) also 8192 -> 16384, which has no in-LDS transform of
+// its full length (measured: 2.28 ms for 16,384 rows instead of 10.2 through the long-transform path).
 //
 // k_zf2<double> (xm_kernels.h) runs the 512-thread x 8-point plan at ~180 VGPRs: ONE workgroup per CU, whose eight
 // waves move in lockstep from barrier to barrier -- counters (profiles/r02/pmc_c128_main.txt): VALU issue 15 % of the
@@ -58,29 +60,70 @@ struct ChainTw {
   }
 };
 
+// waves per SIMD: two workgroups of 256 threads, or one of 1024 (half length 8192: the exchange buffer fills the LDS)
+template <class PL>
+constexpr int zf2d_waves() {
+  return PL::NT >= 1024 ? 4 : 2;
+}
+
+// Twiddle source for plans whose last stage is radix 2 (P/2 butterflies per thread): the twiddle of butterfly u is
+// W_N^{t + NT u} = g W_P^u with g = W_N^t -- one register pair and compile-time rotations instead of P/2 pairs (and, with
+// the folded unit factor f, P/2 more): the 1024-thread plan has 128 VGPRs for everything
+template <class S, class PL, bool R0>
+struct RotTw {
+  static constexpr bool kHasR0 = R0;
+  static constexpr int K = PL::K;
+  static_assert(K > 1 && PL::radix(K - 1) == 2, "last stage radix 2");
+  static constexpr int mid_size() { return PL::tw_offset(K - 1); }
+  const Cx<S>* mid;
+  Cx<S> fg;               // f g
+  Cx<S> r0[PL::P / 2];    // f (all alike: the compiler keeps one)
+  XM_DEV void load(const Cx<S>* __restrict__ tw, int t) {
+    fg = tw[PL::tw_offset(K - 1) + t];
+    if constexpr (R0) {
+#pragma unroll
+      for (int u = 0; u < PL::P / 2; ++u) r0[u] = mk<S>(S(1), S(0));
+    }
+  }
+  XM_DEV void fold(Cx<S> f) {
+    static_assert(R0, "fold needs the r = 0 slot");
+    fg = fg * f;
+#pragma unroll
+    for (int u = 0; u < PL::P / 2; ++u) r0[u] = f;
+  }
+  template <int ST, int U, int R1>
+  XM_DEV Cx<S> get(int k) const {
+    if constexpr (ST == K - 1)
+      return mul_w<U, PL::P, S>(fg);
+    else
+      return mid[PL::tw_offset(ST) + (R1 - 1) * PL::ns(ST) + k];
+  }
+};
+
 template <class PL, int MODE>
-__global__ __launch_bounds__(PL::NT, 2) void k_zf2d(PipeArgs<double> A) {
+__global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<double> A) {
   using T = double;
   constexpr unsigned N = 2 * PL::N, NT = PL::NT;
   constexpr int P = PL::P;
   constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, RAMP = (MODE & ZF2_RAMP) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
   static_assert((WRITE || AMAX) && !(MODE & ZF2_PHASE) && (WRITE || !RAMP), "no phase table; a ramp needs an output");
   static_assert(!AMAX || (MODE & ZF2_VALUE_ONLY), "maxima: value only");
-  static_assert(NT == 256, "two workgroups of four waves per CU");
   using FFT = BlockFFT<T, PL>;
-  using TW = ChainTw<T, PL, RAMP>;
+  // one last-stage butterfly per thread: generated twiddles; P/2 radix-2 ones: one twiddle + compile-time rotations
+  using TW = typename std::conditional<P == PL::radix(PL::K - 1), ChainTw<T, PL, RAMP>, RotTw<T, PL, RAMP>>::type;
+  constexpr bool MID_LDS = TW::mid_size() * (int)sizeof(Cx<T>) <= 8192;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<T>* lds = reinterpret_cast<Cx<T>*>(xm_smem);
   Cx<T>* mid = lds + FFT::lds_elems();
-  T* red_v = reinterpret_cast<T*>(mid + TW::mid_size());
+  T* red_v = reinterpret_cast<T*>(mid + (MID_LDS ? TW::mid_size() : 0));
   int* red_i = reinterpret_cast<int*>(red_v + NT / XM_WAVE + 1);
   unsigned* wq_slot = reinterpret_cast<unsigned*>(red_i + NT / XM_WAVE + 1);
   const unsigned t = threadIdx.x;
 
   TW tw;
-  tw.mid = mid;
+  tw.mid = MID_LDS ? mid : A.tw;  // half length 8192: 64 KB of middle twiddles stay in L2
   tw.load(A.tw, (int)t);
-  for (unsigned i = t; i < (unsigned)TW::mid_size(); i += NT) mid[i] = A.tw[i];
+  for (unsigned i = t; i < (unsigned)(MID_LDS ? TW::mid_size() : 0); i += NT) mid[i] = A.tw[i];
   Cx<T> rot = A.aux[t];  // W_N^t
   if constexpr (RAMP) {  // e^{i b 2t} into the last stage, the odd bins' e^{i b} into their rotation (xm_zf2p.h)
     double sn, cs;
