@@ -43,10 +43,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM traffic of ONE launch of the main kernel on the default workload (65,536 x 4096 -> 8192, c64), from the
 # rocprofv3 PMC passes committed in profiles/r02/pmc_main_kernel.txt (separate --pmc runs, scripts/pmc.sh) for the
 # default (speculative) schedule's main kernel k_zf2p<..., 13, 11> = write + phase ramp + global arg-max key:
-# FETCH_SIZE 1,049,177.9 KB -- gfx950 reports a wide coalesced streaming read at exactly half its bytes
-# (MI355X_MICROARCH.md, section HBM), hence x2 -- plus WRITE_SIZE 4,197,544.7 KB (exact for 16-byte streaming stores).
+# FETCH_SIZE 1,049,200.7 KB -- gfx950 reports a wide coalesced streaming read at exactly half its bytes
+# (MI355X_MICROARCH.md, section HBM), hence x2 -- plus WRITE_SIZE 4,197,403.4 KB (exact for 16-byte streaming stores).
 # A constant typed in here, NOT a measurement of the run that prints it (`traffic_static` in the JSON line).
-PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049177.9 + 4197544.7) * 1024)
+PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049200.7 + 4197403.4) * 1024)
 PMC_SOURCE = "profiles/r02/pmc_main_kernel.txt"
 
 
