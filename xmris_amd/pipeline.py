@@ -498,7 +498,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         if mine:
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
             # at a time and have two device periods each
-            th = fill_team if j == 0 else team
+            th = fill_team if j == 0 else team  # (smaller teams for the searches right behind the first: slower, -1...3 %)
             fut = pool.submit(search, sl, int(k), res.pivot, th) if pool is not None else search(sl, int(k), res.pivot, th)
         pending[j] = (res, fut)
 
