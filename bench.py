@@ -73,6 +73,46 @@ def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, 
     return x, t
 
 
+def synth_hetero(torch, n_voxel, n_time, dt, seed, device, dtype):
+    """A heterogeneous dataset family for the speculative schedule's hit rate (nothing like SURVEY 8(d)'s one spectral
+    shape for every voxel): per voxel 1-8 lines with random amplitudes (0.2-1 x a voxel gain of 0.5-1.5), widths
+    2-60 Hz (FWHM), frequencies +-2 kHz and phases; 5 % noise-only voxels; complex noise of sigma 0.02; and ONE
+    lipid-like voxel -- eight broad (50 Hz) lines of amplitude 3, 90 Hz apart -- whose windowed L1 norm is the largest
+    of the dataset while its peak is not.  Returns (x [n_voxel, n_time], t, lipid_row).  The numpy twin used by the
+    offline study is scripts/study_guess_statistics.py::hetero_numpy."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7919 * (seed + 1))
+    rd = torch.float32 if dtype == torch.complex64 else torch.float64
+    t = np.arange(n_time) * dt
+    td = torch.from_numpy(t).to(device=device, dtype=torch.float64)
+    x = torch.empty((n_voxel, n_time), dtype=dtype, device=device)
+
+    def uni(n, lo, hi):
+        return lo + (hi - lo) * torch.rand(n, generator=gen, device=device, dtype=torch.float64)
+
+    chunk = 4096
+    for s in range(0, n_voxel, chunk):
+        m = min(n_voxel, s + chunk) - s
+        n_lines = torch.randint(1, 9, (m,), generator=gen, device=device)
+        gain = uni(m, 0.5, 1.5)
+        silent = torch.rand(m, generator=gen, device=device, dtype=torch.float64) < 0.05
+        acc = torch.zeros((m, n_time), dtype=torch.complex128, device=device)
+        for j in range(8):
+            on = ((n_lines > j) & ~silent).to(torch.float64)
+            a = uni(m, 0.2, 1.0) * gain * on
+            w, f, ph = uni(m, 2.0, 60.0), uni(m, -2000.0, 2000.0), uni(m, 0.0, 2 * np.pi)
+            rate = torch.complex(-np.pi * w, 2 * np.pi * f)
+            acc += (a * torch.exp(1j * ph))[:, None] * torch.exp(rate[:, None] * td[None, :])
+        noise = torch.randn((m, n_time, 2), generator=gen, device=device, dtype=torch.float64) * (0.02 / np.sqrt(2.0))
+        x[s:s + m] = (acc + torch.view_as_complex(noise)).to(dtype)
+    lipid = int(torch.randint(0, n_voxel, (1,), generator=gen, device=device).item())
+    row = torch.zeros(n_time, dtype=torch.complex128, device=device)
+    for j in range(8):
+        row += 3.0 * torch.exp(torch.complex(torch.tensor(-np.pi * 50.0), torch.tensor(2 * np.pi * (-600.0 + 90.0 * j))).to(device) * td)
+    x[lipid] = row.to(dtype)
+    return x, t, lipid
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as child processes (the environment torchrun
     would give them), relay rank 0's stdout.  Nothing here initialises a GPU."""

@@ -123,6 +123,30 @@ int xm_row_l1(const void* in, int64_t in_row_stride, const void* window, int64_t
 int xm_argmax_key_take(uint64_t* key, int n_per_row, void* out_max2, int64_t* out_flat, const void* in,
                        int64_t in_row_stride, int n_in, void* out_row, int dtype, void* stream);
 
+/* A6, speculative schedule, guess stage (replaces xm_row_l1 + xm_argmax_key_take where xm_guess_supported() says so).
+ * The host searches (p0, p1) on the spectrum of the row that holds the global max |X| (phasing.py:229, 241-242)
+ * BEFORE the spectra exist; these two calls find that row without transforming every row in full:
+ *   xm_guess_rows    est[b] = max_k |X_c[b, k]|^2 of a COARSE spectrum of row b -- its first n_guess (<= 512; 0 = 512)
+ *                    samples times their window weights on a 1024-bin grid (one wave per row; 4 KiB of a 32 KiB row
+ *                    read) -- and the largest estimate in `key` (an arg-max key buffer, zero at launch).  A truncated,
+ *                    coarsely sampled spectrum underestimates a line's height by a bounded factor (scalloping of the
+ *                    grid, the missing tail), so the true arg-max row lies among the rows whose estimate is within
+ *                    that band of the largest one;
+ *   xm_guess_refine  transforms every row with est[b] >= band^2 * max(est) exactly (all n_in samples -> n_out bins, the
+ *                    arithmetic of xm_pipeline_fused; at most 16 rows per resident workgroup) and leaves the winner
+ *                    like xm_argmax_key_take does: out_max2[0] = its max |X|^2 (float), out_flat[0] = row * n_out,
+ *                    out_row[j] = (complex128) in[row, j].  `guess_key` is consumed (left zero), `work_key` is a second
+ *                    key buffer (zero at launch, left zero).
+ * Geometry: "end" zero fill to >= 2x (pad_left = 0, n_out/2 in {512 ... 8192}); `window`: n_out FLOAT32 weights for
+ * either dtype; XM_C128 rows are converted to float on load (a ranking; the main pass's own maxima verify the guess,
+ * xmris_amd/pipeline.py::run_stream).  `est`: n_batch floats.  out_* device-accessible (pinned host memory is fine). */
+int xm_guess_supported(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags, int dtype);
+int xm_guess_rows(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int n_out,
+                  int n_guess, unsigned flags, float* est, uint64_t* key, int dtype, void* stream);
+int xm_guess_refine(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int n_out,
+                    unsigned flags, const float* est, uint64_t* guess_key, float band, uint64_t* work_key,
+                    float* out_max2, int64_t* out_flat, void* out_row, int dtype, void* stream);
+
 /* A6  global arg-max  (phasing.py:229  np.argmax(np.abs(values)), first maximum in C order).
  * Reduces the per-spectrum pairs: out_max2[0] = max_b absmax2[b], out_flat[0] = b*n + argidx[b]
  * of the first such b.  Both outputs are device-accessible scalars. */

@@ -13,11 +13,14 @@ rng = np.random.default_rng(5)
 sets = []
 for k in range(4):
     x = 0.01 * (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt)))
-    lines = np.random.default_rng(k).uniform(-2300.0, 2300.0, 30)
-    x[5] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * f0 * t) for f0 in lines)      # rank 0: largest L1 norm
-    x[40 + k] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * (-400.0 + 50 * k) * t)   # rank 1: the true maximum
-    if k == 3:
-        x[5] *= 0.1                                                                   # last dataset: the guess is right
+    x[5] = 1.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * 310.0 * t)                   # rank 0: the guess stage's winner
+    x[50] = 1.0 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -120.0 * t)                 # rank 1: its guess stage's winner
+    # (without it every row of rank 1 looks like noise to the coarse spectra, all of them become candidates and the
+    # exact check finds the burst)
+    # rank 1: the true maximum -- a burst in samples 600...999, which no guess stage reads (the coarse spectra look at
+    # samples 0...511, the L1 subset at block 0 of every eight 128-sample blocks); the last dataset's burst is weak
+    # and the guess is right
+    x[40 + k, 600:1000] = (60.0 if k < 3 else 2.0) * np.exp(2j * np.pi * (-400.0 + 50 * k) * t[600:1000])
     sets.append(x.astype(np.complex64))
 lo, hi = sharding.shard_bounds(nv, world, rank)
 mine = [dev.to_device(x[lo:hi]) for x in sets]

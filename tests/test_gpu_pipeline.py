@@ -43,6 +43,22 @@ def _three_peak(nv, nt, dt, seed=42, sigma=0.02):
     return x, t
 
 
+def _late_burst(t, amp, f0=650.0, lo=600, hi=1000):
+    """A row whose signal starts after the samples either guess stage looks at (the coarse spectra read samples
+    0...511, the L1 subset block 0 of every eight 128-sample blocks): the tallest peak of its dataset, invisible to
+    the guess -> the verification must catch it."""
+    burst = np.zeros(len(t), dtype=np.complex128)
+    burst[lo:hi] = amp * np.exp(2j * np.pi * f0 * t[lo:hi])
+    return burst
+
+
+def _guess_kind(monkeypatch, kind):
+    if kind == "l1":
+        monkeypatch.setenv("XM_GUESS_L1", "1")  # round 2's guess: the windowed L1 norm's winner, no candidates
+    else:
+        monkeypatch.delenv("XM_GUESS_L1", raising=False)
+
+
 def _check(mods, oracle, x, t, target, lb, dtype, dp_tol=1e-6):
     dev, pipe = mods
     xs = x.astype(dtype)
@@ -168,8 +184,10 @@ def test_run_stream_equals_one_dataset_at_a_time(mods, overlap):
         assert trace[k]["pre0"].elapsed_time(trace[k]["main1"]) > 0
 
 
-def test_run_stream_speculative_hits_and_repairs(mods, oracle):
-    """speculate=True guesses the winning row from the windowed L1 norms, verifies it against the true per-row
+@pytest.mark.parametrize("kind", ["coarse", "l1"])
+def test_run_stream_speculative_hits_and_repairs(mods, oracle, monkeypatch, kind):
+    """[kind = "l1": round 2's guess stage; "coarse": the coarse-spectra candidates see through the thirty-line row and
+    every dataset is a hit]  speculate=True guesses the winning row from the windowed L1 norms, verifies it against the true per-row
     maxima the main pass returns, and repairs a wrong guess in place.  Datasets 0-2: rows of one spectral shape
     (the guess is right); datasets 3-4: one row carries thirty unit resonances (largest L1 norm, peaks of height
     about one) while the global maximum sits in a row with a single line of height 2.5 -- the guess is wrong and must
@@ -178,6 +196,7 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
     import torch
 
     dev, pipe = mods
+    _guess_kind(monkeypatch, kind)
     nv, nt, target = 80, 1024, 2048
     t = np.arange(nt) * 2e-4
     sets = []
@@ -197,7 +216,7 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
     ref = pipe.run_stream(sets, ref_outs, plan)
     got = pipe.run_stream(sets, outs, plan, speculate=True)
     torch.cuda.synchronize()
-    assert [r.speculation for r in got] == ["hit", "hit", "hit", "repaired", "repaired"]
+    assert [r.speculation for r in got] == (["hit", "hit", "hit", "repaired", "repaired"] if kind == "l1" else ["hit"] * 5)
     for k, (a, b) in enumerate(zip(got, ref)):
         assert (a.flat_index, a.target_idx, a.pivot) == (b.flat_index, b.target_idx, b.pivot), k
         assert (a.p0, a.p1) == (b.p0, b.p1), k
@@ -208,14 +227,17 @@ def test_run_stream_speculative_hits_and_repairs(mods, oracle):
     assert got[3].flat_index // target == 50
 
 
-def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods):
-    """The guess kernel sums every 8th 1-KiB block (128 samples) of the leading samples only.  Row 9 of dataset 1 carries ALL its
+@pytest.mark.parametrize("kind", ["coarse", "l1"])
+def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods, monkeypatch, kind):
+    """[kind = "coarse": the coarse spectra read samples 0...511 of a row, the burst sits in 600...999]
+    The L1 guess kernel sums every 8th 1-KiB block (128 samples) of the leading samples only.  Row 9 of dataset 1 carries ALL its
     signal in blocks the guess skips (samples 128...511: a delayed burst), and the tallest peak of the dataset: the
     full L1 norm would find it, the subset cannot.  The verification must catch it and the repaired result must equal
     the classic schedule's; dataset 0 (ordinary decaying rows) is a hit."""
     import torch
 
     dev, pipe = mods
+    _guess_kind(monkeypatch, kind)
     nv, nt, target = 48, 1024, 2048
     t = np.arange(nt) * 2e-4
     sets = []
@@ -223,8 +245,11 @@ def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods):
         x, _ = _three_peak(nv, nt, 2e-4, seed=500 + k)
         x[(5 * k + 2) % nv] *= 2.0
         if k == 1:
-            burst = np.zeros(nt, dtype=np.complex128)
-            burst[128:512] = 12.0 * np.exp(2j * np.pi * 650.0 * t[128:512])  # 384 samples of one frequency
+            if kind == "l1":
+                burst = np.zeros(nt, dtype=np.complex128)
+                burst[128:512] = 12.0 * np.exp(2j * np.pi * 650.0 * t[128:512])  # 384 samples of one frequency
+            else:
+                burst = _late_burst(t, 60.0)
             x[9] = burst
         sets.append(dev.to_device(x.astype(np.complex64)))
     plan = pipe.make_plan(sets[0], t, target, 5.0)
@@ -256,10 +281,8 @@ def test_speculative_schedule_on_the_table_and_per_row_paths(mods, dtype, nt, ta
     for k in range(3):
         x, _ = _three_peak(nv, nt, 2e-4, seed=700 + k)
         x[(3 * k + 1) % nv] *= 2.0
-        if k == 2:  # thirty well separated unit lines: largest L1 norm, not the tallest peak
-            x *= 0.05
-            x[7] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * (-2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)) * t) for j in range(30))
-            x[20] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -400.0 * t)
+        if k == 2:  # a late burst: the tallest peak of the dataset in samples no guess stage reads
+            x[20] = _late_burst(t, 60.0)
         sets.append(dev.to_device(x.astype(dtype)))
     plan = pipe.make_plan(sets[0], t, target, 5.0)
     outs = [torch.empty((nv, target), dtype=sets[0].dtype, device="cuda") for _ in sets]
@@ -340,10 +363,8 @@ def test_speculative_stream_of_many_small_datasets_with_misses(mods, dtype):
     for k in range(14):
         x, _ = _three_peak(nv, nt, 2e-4, seed=900 + k)
         x[(5 * k + 2) % nv] *= 2.0
-        if k in wrong:  # thirty well separated unit lines: largest L1 norm, not the tallest peak
-            x *= 0.05
-            x[7] = sum(np.exp(-20.0 * t) * np.exp(2j * np.pi * (-2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)) * t) for j in range(30))
-            x[20 + k] = 2.5 * np.exp(-20.0 * t) * np.exp(2j * np.pi * -400.0 * t)
+        if k in wrong:  # a late burst: the tallest peak of the dataset in samples no guess stage reads
+            x[20 + k] = _late_burst(t, 60.0)
         sets.append(dev.to_device(x.astype(dtype)))
     plan = pipe.make_plan(sets[0], t, target, 5.0)
     assert pipe._search_workers(plan, nv, sets[0].element_size(), 8)[0] == 4
@@ -357,3 +378,66 @@ def test_speculative_stream_of_many_small_datasets_with_misses(mods, dtype):
         assert (a.flat_index, a.target_idx, a.pivot, a.p0, a.p1) == (b.flat_index, b.target_idx, b.pivot, b.p0, b.p1), k
         tol = 2.5e-7 if dtype == "complex64" else 1e-14
         assert float((outs[k] - refs[k]).abs().max()) <= tol * float(refs[k].abs().max()), k
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_speculative_schedule_on_an_all_zero_dataset(mods, dtype):
+    """np.argmax of an all-zero array is 0 (phasing.py:229): the speculative schedule must guess row 0, verify row 0
+    ("hit") and give the classic schedule's result -- the arg-max keys carry the row even when every |X|^2 is +0.0
+    (round 2 published a key only for values above zero and crashed here).  A dataset of zeros sits between two
+    ordinary ones."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 96, 4096, 8192
+    t = np.arange(nt) * 2e-4
+    a, _ = _three_peak(nv, nt, 2e-4, seed=11)
+    sets = [dev.to_device(a.astype(dtype)), dev.to_device(np.zeros((nv, nt), dtype=dtype)), dev.to_device((2 * a).astype(dtype))]
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=sets[0].dtype, device="cuda") for _ in sets]
+    refs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, refs, plan)
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["hit"] * 3 and got[1].flat_index == ref[1].flat_index == 0
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert (g.flat_index, g.target_idx, g.pivot) == (r.flat_index, r.target_idx, r.pivot), k
+        if k != 1:
+            assert (g.p0, g.p1) == (r.p0, r.p1), k
+    assert float(outs[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype,nv", [("complex64", 8192), ("complex128", 4096)])
+def test_speculative_schedule_hits_on_the_heterogeneous_family(mods, monkeypatch, dtype, nv):
+    """bench.synth_hetero: per-voxel random line counts / widths / amplitudes, noise-only voxels and a lipid-like voxel
+    with the largest windowed L1 norm.  The coarse-spectra guess stage must find the true arg-max voxel on every
+    dataset ("hit") with the classic schedule's (p0, p1) and spectra; round 2's L1 guess misses at least one of them
+    (repaired -- still the same results)."""
+    import torch
+
+    import bench
+
+    dev, pipe = mods
+    nt, target = 4096, 8192
+    tdt = torch.complex64 if dtype == "complex64" else torch.complex128
+    sets, lipids = [], []
+    for seed in range(4):
+        x, t, lip = bench.synth_hetero(torch, nv, nt, 2e-4, seed, "cuda", tdt)
+        sets.append(x)
+        lipids.append(lip)
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=tdt, device="cuda") for _ in range(2)]
+    ref_out = torch.empty_like(outs[0])
+    ref = [pipe.run_stream([x], [ref_out], plan)[0] for x in sets]
+    got = pipe.run_stream(sets, [outs[k % 2] for k in range(4)], plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["hit"] * 4
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert (g.flat_index, g.target_idx, g.pivot, g.p0, g.p1) == (r.flat_index, r.target_idx, r.pivot, r.p0, r.p1), k
+        assert g.flat_index // target != lipids[k]
+    monkeypatch.setenv("XM_GUESS_L1", "1")
+    old = pipe.run_stream(sets, [outs[k % 2] for k in range(4)], plan, speculate=True)
+    torch.cuda.synchronize()
+    assert "repaired" in [r.speculation for r in old]
+    for k, (g, r) in enumerate(zip(old, ref)):
+        assert (g.flat_index, g.p0, g.p1) == (r.flat_index, r.p0, r.p1), k

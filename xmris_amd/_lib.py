@@ -55,6 +55,9 @@ SIGNATURES = {
     "xm_pipeline_ramp_native": (_i, [_p, _l, _i, _i, _i, _u, _i]),
     "xm_row_l1": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "xm_argmax_key_take": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _i, _p]),
+    "xm_guess_supported": (_i, [_p, _l, _i, _i, _i, _u, _i]),
+    "xm_guess_rows": (_i, [_p, _l, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
+    "xm_guess_refine": (_i, [_p, _l, _p, _l, _i, _i, _u, _p, _p, ctypes.c_float, _p, _p, _p, _p, _i, _p]),
     "xm_phase_table": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p, _i]),
     "xm_solver_create": (_p, [_p, _p, _i, ctypes.c_double, _i, _i, _i]),
     "xm_solver_destroy": (None, [_p]),

@@ -407,6 +407,46 @@ int xm_argmax_key_take(uint64_t* key, int n_per_row, void* out_max2, int64_t* ou
   return XM_OK;
 }
 
+int xm_guess_supported(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags, int dtype) {
+  if (!in || (dtype != XM_C64 && dtype != XM_C128) || in_row_stride < n_in) return 0;
+  return xm_zf2p_guess_supported(in, in_row_stride, n_in, n_out, pad_left, flags, dtype);
+}
+
+static float guess_scale(int n_out, unsigned flags) {
+  return (flags & XM_FFT_ORTHO) ? (float)(1.0 / std::sqrt((double)n_out)) : 1.0f;
+}
+
+int xm_guess_rows(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int n_out,
+                  int n_guess, unsigned flags, float* est, uint64_t* key, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n_out, dtype);
+  if (rc) return rc;
+  if (!est || !key || n_guess < 0 || n_batch > 0xffffffffLL)
+    return fail(XM_ERR_INVALID_ARG, "guess_rows: null output or bad sizes");
+  if (!xm_guess_supported(in, in_row_stride, n_in, n_out, 0, flags, dtype))
+    return fail(XM_ERR_INVALID_ARG, "guess_rows: geometry outside xm_guess_supported");
+  if (n_batch == 0) return XM_OK;
+  DeviceGuard guard(in);
+  return xm_zf2p_guess_rows(in, in_row_stride, (const float*)window, n_batch, n_in, n_out, n_guess,
+                            guess_scale(n_out, flags), est, (unsigned long long*)key, dtype, (hipStream_t)stream);
+}
+
+int xm_guess_refine(const void* in, int64_t in_row_stride, const void* window, int64_t n_batch, int n_in, int n_out,
+                    unsigned flags, const float* est, uint64_t* guess_key, float band, uint64_t* work_key,
+                    float* out_max2, int64_t* out_flat, void* out_row, int dtype, void* stream) {
+  int rc = check_common(in, n_batch, n_out, dtype);
+  if (rc) return rc;
+  if (!est || !guess_key || !work_key || work_key == guess_key || !out_flat || n_batch < 1 || n_batch > 0xffffffffLL ||
+      !(band > 0.0f && band <= 1.0f))
+    return fail(XM_ERR_INVALID_ARG, "guess_refine: null pointer, empty batch or band outside (0, 1]");
+  if (!xm_guess_supported(in, in_row_stride, n_in, n_out, 0, flags, dtype))
+    return fail(XM_ERR_INVALID_ARG, "guess_refine: geometry outside xm_guess_supported");
+  DeviceGuard guard(in);
+  return xm_zf2p_guess_refine(in, in_row_stride, (const float*)window, n_batch, n_in, n_out, flags,
+                              guess_scale(n_out, flags), est, (unsigned long long*)guess_key, band,
+                              (unsigned long long*)work_key, out_max2, (long long*)out_flat, out_row, dtype,
+                              (hipStream_t)stream);
+}
+
 int64_t xm_baseline_als_workspace_bytes(int64_t n_batch, int n) {
   if (n_batch < 0 || n < 0) return 0;
   return 5 * n_batch * (int64_t)n * (int64_t)sizeof(double);

@@ -49,6 +49,15 @@ bool xm_supported_in_lds(int n, int dtype);
 int xm_ramp_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 int xm_ramp_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 
+// xm_launch_zf2p.hip: guess stage of the speculative schedule (xm_guess_* in xmris_hip.h)
+int xm_zf2p_guess_supported(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags, int dtype);
+int xm_zf2p_guess_rows(const void* in, int64_t in_stride, const float* window, int64_t n_batch, int n_in, int n_out,
+                       int n_guess, float scale, float* est, unsigned long long* key, int dtype, hipStream_t st);
+int xm_zf2p_guess_refine(const void* in, int64_t in_stride, const float* window, int64_t n_batch, int n_in, int n_out,
+                         unsigned flags, float scale, const float* est, unsigned long long* guess_key, float band,
+                         unsigned long long* work_key, float* out_max2, long long* out_flat, void* out_row, int dtype,
+                         hipStream_t st);
+
 // {head, done} counter pair (zero) for one launch of a persistent kernel that hands out rows dynamically; the
 // kernel's last workgroup leaves it zero again.  Slots come from a per-device ring of 1024.
 int xm_queue_slot(unsigned** out);

@@ -56,6 +56,13 @@ struct PipeArgs {
   double ramp_db;
   T ramp_e[2];
   T ramp_c[32];
+  // Guess stage of the speculative schedule (xm_guess_rows / xm_guess_refine; kernels in xm_zf2p.h, always float):
+  float* est;                         // per-row coarse estimate of max |X|^2: written by the guess pass, read by the refine pass
+  unsigned long long* gkey_in;        // refine pass: the guess pass's key -- its maximum sets the candidate threshold
+  float band2;                        // ... rows with est >= band2 * max(est) are transformed exactly
+  float* take_max2;                   // refine pass, last workgroup out: max |X|^2 of the winning candidate,
+  long long* take_flat;               // ... its row * n, and
+  Cx<double>* take_row;               // ... its n_in samples as complex128 (the search's input is recomputed in fp64)
 };
 
 // ---- (value, index) arg-max helpers: larger value wins, ties -> smaller index; a NaN outranks every number
@@ -1350,7 +1357,7 @@ __global__ __launch_bounds__(1024) void k_key_take(unsigned long long* key, int 
   __syncthreads();
   unsigned long long k = 0;
   for (int i = 0; i < XM_KEY_SLOTS; ++i) k = part[i] > k ? part[i] : k;
-  const long long row = (long long)(0xffffffffu - (unsigned)(k & 0xffffffffu));
+  const long long row = k ? (long long)(0xffffffffu - (unsigned)(k & 0xffffffffu)) : 0;  // nothing published: row 0
   if (in) {
     const Cx<T>* src = in + row * in_stride;
     for (int j = threadIdx.x; j < n_in; j += blockDim.x) out_row[j] = mk<double>((double)src[j].re, (double)src[j].im);

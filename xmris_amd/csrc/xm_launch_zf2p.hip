@@ -23,8 +23,9 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   if (A.n_batch <= 0) return XM_OK;
   constexpr bool L16 = (OPT & ZF2P_LOAD16) != 0;
   using FFT = BlockFFT<xm_f2, PL, L16 ? xm_ilog2(2 * PL::radix(0)) : -1>;
+  constexpr bool CAND = (OPT & ZF2P_CAND) != 0;
   const size_t lds = (size_t)FFT::lds_elems() * sizeof(Cx<xm_f2>) + (size_t)HotTw<T, PL>::mid_lds_size() * sizeof(Cx<T>) +
-                     ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
+                     ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int)) + (CAND ? zf2p_cand_lds_bytes() : 0);
   static XmResidency res;
   int resident = 0;
   rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident);
@@ -38,12 +39,17 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
   A.queue_chunk = (int)chunk;
   const long long nchunks = (A.n_batch + chunk - 1) / chunk;
-  const long long blocks = nchunks < resident ? nchunks : resident;
+  long long blocks = nchunks < resident ? nchunks : resident;
+  if constexpr (CAND) {  // every workgroup scans ceil(n_batch / blocks) estimates: a bit each in its LDS bitmap
+    blocks = A.n_batch < resident ? A.n_batch : resident;
+    if ((A.n_batch + blocks - 1) / blocks > ZF2P_CAND_KMAX)
+      return xm_fail(XM_ERR_INVALID_ARG, "guess_refine: too many rows for one launch");
+  }
   if constexpr ((MODE & ZF2_AMAX) != 0) {
     // value-only maxima are accumulated with one atomic max per wave: the slots start at +0.0
     if (A.amax_value_only && !A.gkey) HIP_TRY(hipMemsetAsync(A.absmax2, 0, (size_t)A.n_batch * sizeof(T), st));
   }
-  if constexpr ((OPT & ZF2P_QUEUE) != 0) {
+  if constexpr ((OPT & (ZF2P_QUEUE | ZF2P_CAND)) != 0) {
     rc = xm_queue_slot(&A.queue);
     if (rc) return rc;
   }
@@ -84,6 +90,106 @@ int launch_plan(PipeArgs<T> A, const double* ramp, hipStream_t st) {
 }
 
 }  // namespace
+
+// ---- guess stage of the speculative schedule ------------------------------------------------------------------
+namespace {
+
+constexpr int kGuessHalf = 512;  // coarse spectra: the first <= 512 samples of a row on a 1024-bin grid
+
+template <class PL, bool IN64>
+int launch_refine(const PipeArgs<T>& A, hipStream_t st) {
+  return launch_mode<PL, ZF2_AMAX, ZF2P_CAND | (IN64 ? ZF2P_IN64 : ZF2P_LOAD16)>(A, st);
+}
+
+template <bool IN64>
+int refine_plan(int h, const PipeArgs<T>& A, hipStream_t st) {
+  switch (h) {
+    case 512: return launch_refine<typename Zf2PlanOf<512>::type, IN64>(A, st);
+    case 1024: return launch_refine<typename Zf2PlanOf<1024>::type, IN64>(A, st);
+    case 2048: return launch_refine<typename Zf2PlanOf<2048>::type, IN64>(A, st);
+    case 4096: return launch_refine<typename PlanOf<4096>::type, IN64>(A, st);
+    case 8192: return launch_refine<typename Zf2PlanOf<8192>::type, IN64>(A, st);
+    default: break;
+  }
+  return xm_fail(XM_ERR_UNSUPPORTED_N, "no half-length plan for " + std::to_string(h));
+}
+
+bool pair_loads_ok(const void* in, int64_t in_stride, int n_in, int pad_left) {
+  return (pad_left % 2 == 0) && (n_in % 2 == 0) && (in_stride % 2 == 0) && ((reinterpret_cast<size_t>(in) & 15u) == 0);
+}
+
+int half_table(int n, const Cx<T>** out) {
+  const void* half = nullptr;
+  const int rc = xm_table_get(TK_HALF, n, 0, XM_C64, xm_gen_half, nullptr, &half);
+  *out = (const Cx<T>*)half;
+  return rc;
+}
+
+}  // namespace
+
+int xm_zf2p_guess_supported(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags, int dtype) {
+  const int h = n_out / 2;
+  if (n_out % 2 || pad_left != 0 || n_in > h || n_in < 2) return 0;
+  if (h != 512 && h != 1024 && h != 2048 && h != 4096 && h != 8192) return 0;
+  if (flags & (XM_FFT_SHIFT_IN | XM_FFT_INVERSE)) return 0;
+  if (dtype == XM_C128) return (reinterpret_cast<size_t>(in) & 15u) == 0;
+  const int ng = n_in < kGuessHalf ? n_in : kGuessHalf;
+  return pair_loads_ok(in, in_stride, n_in, 0) && ng % 2 == 0;
+}
+
+int xm_zf2p_guess_rows(const void* in, int64_t in_stride, const float* window, int64_t n_batch, int n_in, int n_out,
+                       int n_guess, float scale, float* est, unsigned long long* key, int dtype, hipStream_t st) {
+  PipeArgs<T> A;
+  std::memset(&A, 0, sizeof(A));
+  A.in = (const Cx<T>*)in;
+  A.window = window;
+  A.in_stride = in_stride;
+  A.n_batch = n_batch;
+  A.n = 2 * kGuessHalf;
+  int ng = n_guess > 0 && n_guess < kGuessHalf ? n_guess : kGuessHalf;
+  if (ng > n_in) ng = n_in;
+  if (dtype == XM_C64) ng &= ~1;  // pair loads
+  A.n_in = ng;
+  A.amax_value_only = 1;
+  A.scale = scale;
+  A.gkey = key;
+  A.est = est;
+  A.absmax2 = est;  // (the kernel's "maxima wanted" marker)
+  (void)n_out;
+  int rc = half_table(A.n, &A.aux);
+  if (rc) return rc;
+  using PL = typename Zf2PlanOf<kGuessHalf>::type;
+  return dtype == XM_C64 ? launch_mode<PL, ZF2_AMAX, ZF2P_EST | ZF2P_LOAD16>(A, st)
+                         : launch_mode<PL, ZF2_AMAX, ZF2P_EST | ZF2P_IN64>(A, st);
+}
+
+int xm_zf2p_guess_refine(const void* in, int64_t in_stride, const float* window, int64_t n_batch, int n_in, int n_out,
+                         unsigned flags, float scale, const float* est, unsigned long long* guess_key, float band,
+                         unsigned long long* work_key, float* out_max2, long long* out_flat, void* out_row, int dtype,
+                         hipStream_t st) {
+  PipeArgs<T> A;
+  std::memset(&A, 0, sizeof(A));
+  A.in = (const Cx<T>*)in;
+  A.window = window;
+  A.in_stride = in_stride;
+  A.n_batch = n_batch;
+  A.n = n_out;
+  A.n_in = n_in;
+  A.out_shift = (flags & XM_FFT_SHIFT_OUT) ? n_out / 2 : 0;
+  A.amax_value_only = 1;
+  A.scale = scale;
+  A.gkey = work_key;
+  A.gkey_in = guess_key;
+  A.est = const_cast<float*>(est);
+  A.absmax2 = const_cast<float*>(est);  // (the kernel's "maxima wanted" marker)
+  A.band2 = band * band;
+  A.take_max2 = out_max2;
+  A.take_flat = out_flat;
+  A.take_row = (Cx<double>*)out_row;
+  int rc = half_table(n_out, &A.aux);
+  if (rc) return rc;
+  return dtype == XM_C64 ? refine_plan<false>(n_out / 2, A, st) : refine_plan<true>(n_out / 2, A, st);
+}
 
 bool xm_zf2p_eligible(const PipeArgs<float>& A, int64_t in_stride) {
   static const bool gen1 = getenv("XM_ZF2_GEN1") != nullptr;  // tuning switch: the first-generation kernel

@@ -24,10 +24,25 @@
 //     after next right after the prefetch is issued; the ticket comes back during the transform and is published
 //     through LDS in front of an existing barrier (BlockFFT's hook), so the claim costs no barrier and no stall.
 //     The last workgroup to leave resets the counters for the next launch.
+//   * the guess stage of the speculative schedule runs on the same kernel (round 3):
+//       ZF2P_EST  -- "coarse spectra": the first n_in (<= 512) samples of every row through the half-length-512 plan
+//                    (one wave per row), max |X|^2 of the 1024-bin transform stored per row (PipeArgs::est) and merged
+//                    into the arg-max key.  A truncated, coarsely sampled spectrum underestimates a line's height by a
+//                    factor in [~0.8, 1] (scalloping + the missing tail), so every row whose estimate lies within that
+//                    band of the largest one is a CANDIDATE for the global arg-max;
+//       ZF2P_CAND -- "refine": every workgroup scans its share of the estimates (rows dealt round-robin with a
+//                    rotation, so neighbouring bright voxels go to different workgroups), transforms its candidates
+//                    exactly (full row, the arithmetic of the main pass) and merges (max |X|^2, row) into a key; the
+//                    last workgroup out decodes the key, clears both keys and gathers the winning FID as complex128;
+//       ZF2P_IN64 -- rows are complex128 in memory, converted to float on load (ranking statistics for the
+//                    complex128 schedule: the verification against the fp64 main pass stays exact).
 #pragma once
 #include "xm_kernels.h"
 
-enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8 };  // OPT bits
+enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8, ZF2P_EST = 16, ZF2P_CAND = 32, ZF2P_IN64 = 64 };  // OPT bits
+constexpr int ZF2P_CAND_CAP = 16;      // candidates one workgroup transforms at most
+constexpr int ZF2P_CAND_KMAX = 16384;  // row blocks (of gridDim.x rows each) one workgroup can scan: bits of its LDS bitmap
+constexpr size_t zf2p_cand_lds_bytes() { return (ZF2P_CAND_CAP + 3 + ZF2P_CAND_KMAX / 32) * sizeof(unsigned); }
 
 constexpr int xm_ilog2(int v) {
   int s = 0;
@@ -45,6 +60,10 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   constexpr bool RAMP = (MODE & ZF2_RAMP) != 0;
   constexpr bool L16 = (OPT & ZF2P_LOAD16) != 0;
   constexpr int AUX = (OPT & ZF2P_NT) ? 2 : 0;
+  constexpr bool EST = (OPT & ZF2P_EST) != 0, CAND = (OPT & ZF2P_CAND) != 0, IN64 = (OPT & ZF2P_IN64) != 0;
+  static_assert(!EST || (NT == XM_WAVE && AMAX && !WRITE), "the per-row estimate is stored by the row's one wave");
+  static_assert(!CAND || (AMAX && !WRITE && (OPT & ZF2P_QUEUE) == 0), "candidates: maxima only, static order");
+  static_assert(!(IN64 && L16), "pair loads are complex64 loads");
   static_assert(!(PHASE && RAMP), "phase table and ramp are exclusive");
   static_assert(!RAMP || WRITE, "a ramp needs an output");
   static_assert(P % 2 == 0 && NT >= XM_WAVE, "pair loads need an even number of points per thread, whole waves");
@@ -86,35 +105,85 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   // FID sample j = col + NT*q of a row lives at row[j - pad_left]; positions outside the acquired samples read a
   // clamped (valid) address and are zeroed by their window weight.
   constexpr int NRAW = L16 ? P / 2 : P;
-  typedef unsigned raw_t __attribute__((ext_vector_type(L16 ? 4 : 2)));
+  typedef unsigned raw_t __attribute__((ext_vector_type((L16 || IN64) ? 4 : 2)));
   raw_t raw[NRAW];
   // L16: element offset of this lane's pair for j = 0: columns (c0, c0 + 1) of row `half`
   const unsigned e0 = (t & ~(XM_WAVE - 1u)) + 2u * (lane & 31u) + NT * half - (unsigned)A.pad_left;
   auto fetch = [&](long long s2, unsigned ee0, unsigned cc, unsigned nin) {
-    const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
+    constexpr size_t EB = IN64 ? 16u : 8u;  // bytes per stored sample
+    const char* __restrict__ row = reinterpret_cast<const char*>(A.in) + (size_t)(s2 * A.in_stride) * EB;
     if constexpr (L16) {
 #pragma unroll
       for (int j = 0; j < P / 2; ++j) {
         const unsigned e = min(ee0 + 2u * NT * j, nin - 2u);
-        raw[j] = *reinterpret_cast<const raw_t*>(reinterpret_cast<const char*>(row) + (size_t)e * 8u);
+        raw[j] = *reinterpret_cast<const raw_t*>(row + (size_t)e * 8u);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const unsigned e = min(cc + NT * q, nin - 1u);
-        raw[q] = *reinterpret_cast<const raw_t*>(reinterpret_cast<const char*>(row) + (size_t)e * 8u);
+        raw[q] = *reinterpret_cast<const raw_t*>(row + (size_t)e * EB);
       }
     }
   };
-  unsigned best_key = 0, best_row = 0;  // A.gkey: this wave's best (max |X|^2 bits, row), wave-uniform
+  // A.gkey: this wave's best (max |X|^2 bits, row), wave-uniform.  `have`: an all-zero launch still publishes its
+  // first row (np.argmax of zeros is 0; a key of value 0 is non-zero through its row word)
+  unsigned best_key = 0, best_row = 0;
+  bool have = false;
+  // rows this workgroup iterates over: all of the launch's (static stride or the queue), or its own candidates
+  long long n_rows = A.n_batch;
+  unsigned* cand = lds_next + 1;
+  if constexpr (CAND) {
+    unsigned* cand_n = cand + ZF2P_CAND_CAP;
+    unsigned* top_bits = cand_n + 1;
+    unsigned* bitmap = top_bits + 1;
+    const unsigned G = gridDim.x, b = blockIdx.x;
+    const unsigned kmax = (unsigned)((A.n_batch + G - 1) / G);  // <= ZF2P_CAND_KMAX (checked by the launcher)
+    for (unsigned i = t; i < (kmax + 31u) / 32u; i += NT) bitmap[i] = 0u;
+    if (t < XM_WAVE) {  // the largest estimate of the launch: the high word of the guess pass's key
+      const unsigned long long k = __hip_atomic_load(A.gkey_in + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned hi = wave_reduce_u32<true>((unsigned)(k >> 32));
+      if (t == 0) *top_bits = hi;
+    }
+    __syncthreads();
+    const float thr = A.band2 * __uint_as_float(*top_bits);
+    // row of (workgroup b, block k): k G + (b + 37 k) mod G -- a bijection per block, rotated from block to block
+    for (unsigned k = t; k < kmax; k += NT) {
+      const long long r = (long long)k * G + (b + 37u * k) % G;
+      if (r < A.n_batch) {
+        const float e = A.est[r];
+        if (e >= thr || e != e) atomicOr(&bitmap[k >> 5], 1u << (k & 31u));  // a NaN row is always a candidate
+      }
+    }
+    __syncthreads();
+    if (t == 0) {  // ascending rows, at most ZF2P_CAND_CAP of them
+      unsigned n = 0;
+      for (unsigned w = 0; w < (kmax + 31u) / 32u && n < (unsigned)ZF2P_CAND_CAP; ++w) {
+        unsigned bits = bitmap[w];
+        while (bits && n < (unsigned)ZF2P_CAND_CAP) {
+          const unsigned k = w * 32u + (unsigned)__builtin_ctz(bits);
+          bits &= bits - 1u;
+          cand[n++] = (unsigned)((long long)k * G + (b + 37u * k) % G);
+        }
+      }
+      *cand_n = n;
+    }
+    __syncthreads();
+    n_rows = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*cand_n);
+  }
+  auto rowid = [&](long long v) -> long long {  // iteration index -> row of the batch
+    if constexpr (CAND) return (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)cand[v]);
+    else return v;
+  };
   // Work is handed out in CHUNKS of `ch` consecutive rows (one ticket per chunk: a single counter takes ~90 tickets
   // per microsecond, short rows would outrun it).  c_cur = the chunk being transformed, c_nxt = the one after it
   // (its first row is prefetched during the last row of c_cur): static stride for the first round, then claimed.
-  const long long ch = A.queue_chunk > 0 ? A.queue_chunk : 1;
-  long long c_cur = blockIdx.x, c_nxt = c_cur + gridDim.x, c_nn = c_nxt + gridDim.x;
+  const long long ch = (!CAND && A.queue_chunk > 0) ? A.queue_chunk : 1;
+  const long long c_first = CAND ? 0 : blockIdx.x, c_step = CAND ? 1 : gridDim.x;
+  long long c_cur = c_first, c_nxt = c_cur + c_step, c_nn = c_nxt + c_step;
   long long s = c_cur * ch;
   unsigned off = 0;  // row within the chunk
-  if (s < A.n_batch) fetch(s, e0, coff, n_in);
+  if (s < n_rows) fetch(rowid(s), e0, coff, n_in);
   if constexpr (QUEUE) {
     if (t == 0) *lds_next = atomicAdd(A.queue, 1u) + gridDim.x;
     __syncthreads();
@@ -122,8 +191,8 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     __syncthreads();
   }
 
-  while (s < A.n_batch) {
-    const bool chunk_end = (off + 1 == (unsigned)ch) || (s + 1 >= A.n_batch);
+  while (s < n_rows) {
+    const bool chunk_end = (off + 1 == (unsigned)ch) || (s + 1 >= n_rows);
     const long long s_nxt = chunk_end ? c_nxt * ch : s + 1;  // the row prefetched during this transform
     // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in ~100 hoisted registers
     unsigned tt = t, cc = col, sh = (unsigned)A.out_shift, nin = n_in, pl = (unsigned)A.pad_left, ee0 = e0;
@@ -147,6 +216,13 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         xr[2 * j] = mk<T>(__uint_as_float(re[0]), __uint_as_float(im[0]));
         xr[2 * j + 1] = mk<T>(__uint_as_float(re[1]), __uint_as_float(im[1]));
       }
+    } else if constexpr (IN64) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        Cx<double> d;
+        __builtin_memcpy(&d, &raw[q], 16);
+        xr[q] = mk<T>((T)d.re, (T)d.im);
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < P; ++q) xr[q] = mk<T>(__uint_as_float(raw[q].x), __uint_as_float(raw[q].y));
@@ -159,7 +235,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       v[q].re = V{e.re, o.re};
       v[q].im = V{e.im, o.im};
     });
-    if (s_nxt < A.n_batch) fetch(s_nxt, ee0, cc - pl, nin);
+    if (s_nxt < n_rows) fetch(rowid(s_nxt), ee0, cc - pl, nin);
     if constexpr (QUEUE) {
       // first row of a chunk: thread 0 claims the chunk after next right after the prefetch is issued; the ticket
       // is back by the last exchange and goes through LDS in front of one of the transform's own barriers
@@ -188,9 +264,14 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         // order like their bit patterns) -- no LDS slot, no workgroup barrier
         const unsigned key = wave_reduce_u32<true>(__float_as_uint(bv));
         if (A.gkey) {  // rows come in ascending order: strict > keeps the lowest row among equal values
-          const bool take = key > best_key;
+          const unsigned r = (unsigned)rowid(s);
+          const bool take = !have || key > best_key;
           best_key = take ? key : best_key;
-          best_row = take ? (unsigned)s : best_row;
+          best_row = take ? r : best_row;
+          have = true;
+          if constexpr (EST) {
+            if (lane == 0u) A.est[r] = __uint_as_float(key);
+          }
         } else {
           if ((tt & (XM_WAVE - 1)) == 0u) atomicMax(reinterpret_cast<unsigned*>(A.absmax2 + s), key);
           if (tt == 0u) A.argidx[s] = 0;
@@ -248,7 +329,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     if (chunk_end) {
       c_cur = c_nxt;
       c_nxt = c_nn;
-      if constexpr (!QUEUE) c_nn = c_nxt + gridDim.x;
+      if constexpr (!QUEUE) c_nn = c_nxt + c_step;
       off = 0;
     } else {
       ++off;
@@ -256,18 +337,18 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     s = s_nxt;
   }
   if constexpr (AMAX) {
-    if (A.gkey && best_key != 0u && lane == 0u)
+    if (A.gkey && have && lane == 0u)
       atomicMax(A.gkey + (blockIdx.x % XM_KEY_SLOTS) * XM_KEY_STRIDE,
                 ((unsigned long long)best_key << 32) | (unsigned long long)(0xffffffffu - best_row));
   }
-  if constexpr (QUEUE) {  // the last workgroup out leaves the counters at zero for the next launch
-    if constexpr (AMAX) {
-      // ... and, asked to (A.key_result), merges the partial keys into the caller's result record: every wave's
-      // atomic is acknowledged (vmcnt) before its workgroup counts itself out, so the last one sees them all
-      if (A.gkey && A.key_result) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
+  if constexpr (QUEUE || CAND) {  // the last workgroup out leaves the counters at zero for the next launch
+    // ... and, asked to (A.key_result / A.take_flat), merges the partial keys into the caller's result record: every
+    // wave's atomic is acknowledged (vmcnt) before its workgroup counts itself out, so the last one sees them all
+    bool decode = false;
+    if constexpr (AMAX) decode = A.gkey && (A.key_result || (CAND && A.take_flat));
+    if (decode) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
     unsigned last = 0;
     if (t == 0) {
@@ -277,13 +358,16 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         __hip_atomic_store(A.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(A.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if constexpr (CAND) *lds_next = last;
     }
     if constexpr (AMAX) {
-      if (A.gkey && A.key_result && t < XM_WAVE) {  // first wave (XM_KEY_SLOTS == 64 == one key per lane)
+      if (decode && t < XM_WAVE) {  // first wave (XM_KEY_SLOTS == 64 == one key per lane)
         last = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
         if (last) {
           unsigned long long k = __hip_atomic_load(A.gkey + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(A.gkey + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if constexpr (CAND)  // every workgroup has read the guess pass's key by now
+            __hip_atomic_store(A.gkey_in + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
           for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
             const unsigned hi = (unsigned)__shfl_xor((int)(k >> 32), m, XM_WAVE), lo = (unsigned)__shfl_xor((int)(unsigned)k, m, XM_WAVE);
@@ -291,8 +375,32 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
             k = o > k ? o : k;
           }
           if (t == 0) {
-            A.key_result->max2 = __uint_as_float((unsigned)(k >> 32));
-            A.key_result->flat = (long long)(0xffffffffu - (unsigned)(k & 0xffffffffu)) * (long long)N;
+            const unsigned row = k ? 0xffffffffu - (unsigned)(k & 0xffffffffu) : 0u;  // nothing published: row 0
+            if (A.key_result) {
+              A.key_result->max2 = __uint_as_float((unsigned)(k >> 32));
+              A.key_result->flat = (long long)row * (long long)N;
+            }
+            if constexpr (CAND) {
+              if (A.take_max2) A.take_max2[0] = __uint_as_float((unsigned)(k >> 32));
+              A.take_flat[0] = (long long)row * (long long)N;
+              cand[0] = row;
+            }
+          }
+        }
+      }
+      if constexpr (CAND) {  // ... and gathers the winning FID as complex128 (the whole workgroup)
+        if (decode) {
+          __syncthreads();
+          if (*lds_next != 0u && A.take_row) {
+            const size_t r = (size_t)cand[0] * (size_t)A.in_stride;
+            for (unsigned j = t; j < n_in; j += NT) {
+              if constexpr (IN64) {
+                A.take_row[j] = reinterpret_cast<const Cx<double>*>(A.in)[r + j];
+              } else {
+                const Cx<T> x = A.in[r + j];
+                A.take_row[j] = mk<double>((double)x.re, (double)x.im);
+              }
+            }
           }
         }
       }

@@ -400,6 +400,43 @@ def row_l1(x2, window=None, pad_left: int = 0, out=None, n_used: int | None = No
     return out
 
 
+def guess_supported(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho: bool = True) -> bool:
+    """True when the coarse-spectra guess stage (`guess_rows` + `guess_refine`) takes this geometry ("end" zero fill to
+    >= 2x with an in-LDS half-length plan; complex64 rows 16-byte aligned)."""
+    _require_device(x2)
+    if x2.dim() != 2 or not x2.is_contiguous():
+        return False
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    return bool(_lib.load().xm_guess_supported(x2.data_ptr(), x2.shape[1], x2.shape[1], int(n_out), int(pad_left), flags,
+                                               _dtype_code(x2)))
+
+
+def guess_rows(x2, n_out: int, window32, est, key, n_guess: int = 0, shift_out: bool = True, ortho: bool = True):
+    """`xm_guess_rows`: est[b] = max |X_c|^2 of the coarse spectrum of row b (its first <= 512 windowed samples on a
+    1024-bin grid), the largest estimate merged into `key`.  `window32`: float32 weights over the zero-filled axis
+    (for complex128 rows too); `est`: float32 [n_batch]."""
+    _require_device(x2)
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    nb, n_in = x2.shape
+    _lib.call("xm_guess_rows", x2.data_ptr(), n_in, window32.data_ptr() if window32 is not None else None, nb, n_in,
+              int(n_out), int(n_guess), flags, est.data_ptr(), key.data_ptr(), _dtype_code(x2), _stream(x2))
+    return est
+
+
+def guess_refine(x2, n_out: int, window32, est, guess_key, work_key, gmax, gflat, out_row, band: float = 0.75,
+                 shift_out: bool = True, ortho: bool = True):
+    """`xm_guess_refine`: every row whose estimate is within `band` of the largest one is transformed exactly; the
+    winner's max |X|^2 -> `gmax` (float32), row * n_out -> `gflat` (int64), its FID as complex128 -> `out_row`
+    ([1, n_in]); both keys are left zero."""
+    _require_device(x2)
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    nb, n_in = x2.shape
+    _lib.call("xm_guess_refine", x2.data_ptr(), n_in, window32.data_ptr() if window32 is not None else None, nb, n_in,
+              int(n_out), flags, est.data_ptr(), guess_key.data_ptr(), float(band), work_key.data_ptr(),
+              gmax.data_ptr(), gflat.data_ptr(), out_row.data_ptr(), _dtype_code(x2), _stream(x2))
+    return out_row
+
+
 def new_argmax_key(device):
     """A zeroed arg-max key buffer (XM_KEY_BYTES) for `row_l1(key=)` / `pipeline_fused(global_key=)`."""
     return _torch().zeros(8192 // 8, dtype=_torch().int64, device=device)

@@ -107,7 +107,8 @@ class Selection:
                 torch.empty((1, plan.n_out), dtype=torch.complex128, pin_memory=True),
                 torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device))
 
-    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False, key=None, slot=None):
+    def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False, key=None, slot=None,
+                 refine=None):
         import torch
 
         n = plan.n_out
@@ -120,7 +121,7 @@ class Selection:
         # complex128 spectrum kernel stores its 128 KiB row there -- no memcpy nodes on the stream.  The
         # buffers are reused across datasets (two sets: a streaming caller keeps at most two selections
         # in flight); allocating pinned memory per call costs more than the transfers.
-        rdt = absmax2.dtype if key is None else torch.float32
+        rdt = absmax2.dtype if (key is None and refine is None) else torch.float32
         if slot is None:
             pool = plan.extra.setdefault("pinned", [])
             turn = plan.extra["turn"] = (plan.extra.get("turn", -1) + 1) % 2
@@ -128,7 +129,10 @@ class Selection:
                 pool.append(Selection.new_slot(x2, plan, rdt))
             slot = pool[turn]
         self.h_max, self.h_flat, self.h_slice, x1 = slot
-        if key is not None:  # the producer left the winner in a 64-bit key: decode + gather in one small launch
+        if refine is not None:  # coarse estimates -> exact check of the candidates -> winner decoded + gathered
+            window32, est, gkey, wkey, band = refine
+            dev.guess_refine(x2, n, window32, est, gkey, wkey, self.h_max, self.h_flat, x1, band=band)
+        elif key is not None:  # the producer left the winner in a 64-bit key: decode + gather in one small launch
             dev.argmax_key_take(key, n, self.h_max, self.h_flat, x2, out_row=x1)
         else:
             dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
@@ -412,12 +416,21 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     ring = g_ahead + 2
-    use_keys = x0.dtype == torch.complex64 and dev.ramp_native(x0, plan.n_out, plan.pad_left)
-    key = ("spec_bufs", nb, str(rd), ring)
+    distinct = list({id(x): x for x in inputs}.values())
+    # the main pass leaves its true global arg-max in a key (no per-row arrays): every dataset must take that kernel
+    use_keys = x0.dtype == torch.complex64 and all(dev.ramp_native(x, plan.n_out, plan.pad_left) for x in distinct)
+    # guess stage: coarse spectra + exact check of the candidates (both precisions); else the windowed L1 norm's winner
+    use_guess = (os.environ.get("XM_GUESS_L1") is None and plan.window is not None
+                 and all(dev.guess_supported(x, plan.n_out, plan.pad_left) for x in distinct))
+    band = float(os.environ.get("XM_GUESS_BAND", "0.75"))
+    key = ("spec_bufs", nb, str(rd), ring, use_guess)
     bufs = plan.extra.get(key)
     if bufs is None:
+        sel_rd = torch.float32 if use_guess else rd
         bufs = plan.extra[key] = dict(
-            norm=[None if use_keys else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
+            norm=[None if (use_keys or use_guess) else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
+            est=[torch.empty(nb, dtype=torch.float32, device=x0.device) if use_guess else None for _ in range(ring)],
+            wkey=dev.new_argmax_key(x0.device) if use_guess else None,
             zero_idx=torch.zeros(nb, dtype=torch.int32, device=x0.device),
             tmax=[None if use_keys else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
             tidx=[None if use_keys else torch.empty(nb, dtype=torch.int32, device=x0.device) for _ in range(ring)],
@@ -425,10 +438,12 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             vflat=[torch.empty(1, dtype=torch.int64, pin_memory=True) for _ in range(ring)],
             # complex64: the guess kernel and the main kernel leave their winners in arg-max key buffers (no per-row
             # arrays, no separate reductions); every key is cleared by the launch that decodes it
-            gkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
+            gkey=[dev.new_argmax_key(x0.device) if (use_keys or use_guess) else None for _ in range(ring)],
             vkey=[dev.new_argmax_key(x0.device) if use_keys else None for _ in range(ring)],
             vres=[dev.new_key_result() if use_keys else None for _ in range(ring)],
-            sel_slots=[Selection.new_slot(x0, plan, rd) for _ in range(ring)])
+            sel_slots=[Selection.new_slot(x0, plan, sel_rd) for _ in range(ring)])
+    if use_guess and plan.extra.get("window32") is None:
+        plan.extra["window32"] = plan.window.to(torch.float32).contiguous()
     sel = [None] * ring
     events = [dict() for _ in range(n_sets)]
     results = [None] * n_sets
@@ -465,12 +480,17 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         if trace is not None:
             ev["pre0"], ev["pre1"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev["pre0"].record()
-        dev.row_l1(inputs[j], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used, sub_step=sub_step,
-                   key=bufs["gkey"][b])
+        if use_guess:
+            dev.guess_rows(inputs[j], n, plan.extra["window32"], bufs["est"][b], bufs["gkey"][b])
+        else:
+            dev.row_l1(inputs[j], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used, sub_step=sub_step,
+                       key=bufs["gkey"][b])
         if trace is not None:
             ev["pre1"].record()
         sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
-                           key=bufs["gkey"][b], slot=bufs["sel_slots"][b])
+                           key=None if use_guess else bufs["gkey"][b], slot=bufs["sel_slots"][b],
+                           refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
+                           if use_guess else None)
 
     full_team = aps.default_threads()
     # the pipeline-filling search (the first main pass waits for it) takes the whole CPU share for its millisecond:
