@@ -50,20 +50,20 @@ PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049200.7 + 4197403.4) * 1024)
 PMC_SOURCE = "profiles/r02/pmc_main_kernel.txt"
 
 
-def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, dtype):
+def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, dtype, seed=42, star=None):
     """three damped lines + complex noise, per-voxel amplitude, one designated
-    brightest voxel (unique global maximum).  Generated on the device."""
+    brightest voxel (unique global maximum; `star`, default n_voxel_total // 3).  Generated on the device."""
     t = np.arange(n_time) * dt
     amps, damps, freqs = (1.0, 0.5, 0.3), (20.0, 33.0, 25.0), (300.0, -800.0, 1100.0)
     base = sum(a * np.exp(-d * t) * np.exp(2j * np.pi * f * t) for a, d, f in zip(amps, damps, freqs))
     base_d = torch.from_numpy(base).to(device=device, dtype=dtype)
     v = torch.arange(voxel_offset, voxel_offset + n_voxel, device=device, dtype=torch.float64)
     amp = 0.5 + torch.remainder(v, 997.0) / 997.0
-    star = n_voxel_total // 3
+    star = n_voxel_total // 3 if star is None else int(star)
     amp = torch.where(v == float(star), torch.full_like(amp, 2.0), amp)
     rd = torch.float32 if dtype == torch.complex64 else torch.float64
     gen = torch.Generator(device=device)
-    gen.manual_seed(42 + voxel_offset)
+    gen.manual_seed(seed + voxel_offset)
     x = torch.empty((n_voxel, n_time), dtype=dtype, device=device)
     chunk = 8192
     for s in range(0, n_voxel, chunk):
@@ -168,6 +168,10 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=200.0,
                     help="untimed steps run before the warm-up until this much wall time has passed (clocks, caches, "
                          "page tables and the software pipeline reach their steady state however short --warmup is)")
+    ap.add_argument("--datasets", type=int, default=4,
+                    help="distinct synthetic datasets the steps rotate through (different noise, different brightest voxel)")
+    ap.add_argument("--hetero-sets", type=int, default=32,
+                    help="footnote: datasets of the heterogeneous family (synth_hetero) the hit rate is measured on")
     ap.add_argument("--no-footnotes", action="store_true",
                     help="skip the extra measurements after the timed region (classic schedule, single dataset, forced "
                          "miss, complex128)")
@@ -245,7 +249,15 @@ def main():
     bytes_per = 8 if args.dtype == "c64" else 16
     nv, nt, N = args.voxels, args.n_time, args.target_points
     dt = 1.0 / 5000.0
-    x, t = synth_fids(torch, nv, nt, dt, rank * nv, world * nv, device, cdtype)
+    # a ring of distinct datasets (SURVEY 8(d)'s recipe: own noise each, the brightest voxel somewhere else each time,
+    # on another rank when there are several); the steps rotate through it
+    n_total = world * nv
+    xs = []
+    for k in range(max(1, args.datasets)):
+        xk, t = synth_fids(torch, nv, nt, dt, rank * nv, n_total, device, cdtype, seed=42 + 1009 * k,
+                           star=(n_total // 3 + k * (n_total // 5) + 7 * k) % n_total)
+        xs.append(xk)
+    x = xs[0]
 
     # host metadata exactly as the accessor layer computes it (fid.py:257-263, 136; fourier.py:95-98, 31)
     tt = t[0] + np.arange(N) * (t[1] - t[0])
@@ -282,10 +294,11 @@ def main():
         """n_steps complete passes of the hot path = xmris_amd.pipeline.run_stream over n_steps independent
         datasets (the library's software-pipelined executor: with `overlap` the device runs the pre-pass of
         dataset i+1 and the main pass of dataset i-1 while the host searches (p0, p1) for dataset i; every
-        step does all of its own work inside this call, nothing is left over or reused).  NB: the same
-        synthetic dataset is passed for every step; outputs alternate between two buffers."""
+        step does all of its own work inside this call, nothing is left over or reused).  The steps rotate
+        through the ring of distinct datasets; outputs alternate between two buffers."""
         trace = []
-        results = pipeline.run_stream([x] * n_steps, [out if k % 2 == 0 else out_b for k in range(n_steps)], plan,
+        results = pipeline.run_stream([xs[k % len(xs)] for k in range(n_steps)],
+                                      [out if k % 2 == 0 else out_b for k in range(n_steps)], plan,
                                       exchange=exchange if world > 1 else None,
                                       broadcast=broadcast if world > 1 else None, rank_offset_rows=rank * nv,
                                       overlap=overlap, trace=trace, speculate=speculate)
@@ -387,6 +400,7 @@ def main():
             "workload": f"BASELINE configs[2]: {nv} voxels x {nt}-pt complex FID -> zero-fill {N}, lb={args.lb}, "
                         f"autophase(acme, single), storage {args.dtype}, per GPU",
             "voxels_per_gpu": nv, "n_time": nt, "target_points": N, "parallelism": f"voxel-shard x{world}",
+            "distinct_datasets": len(xs),
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel,
@@ -425,7 +439,9 @@ def main():
     if world > 1:
         result["rccl_ranks"] = rccl_ranks  # None: the barrier / timing reduction ran on gloo (see stderr)
     if not args.no_footnotes and world == 1:
-        result.update(footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms, alg_bytes))
+        result.update(footnotes(torch, pipeline, dev, xs, t, (out, out_b), plan, N, args, speculate, main_ms, alg_bytes))
+        if speculate and "heterogeneous" in result:
+            result["speculation"]["hit_rate_heterogeneous"] = result["heterogeneous"]["hit_rate"]
         if speculate and "speculation_miss" in result:  # the hit counts above are the timed region's; this is the price
             result["speculation"]["miss_penalty_ms"] = result["speculation_miss"]["miss_penalty_ms"]
 
@@ -440,18 +456,25 @@ def main():
         dist.destroy_process_group()
 
 
-def footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms, alg_bytes):
+def footnotes(torch, pipeline, dev, xs, t, outs, plan, N, args, speculate, main_ms, alg_bytes):
     """What the headline does not say by itself, measured after the timed region on the same buffers:
       value_classic_schedule   the same workload with the arg-max pre-pass instead of the verified guess
       single_dataset_ms        ONE dataset end to end (guess -> search -> main -> verify), nothing to overlap with
-      speculation.miss_*       the synthetic voxels share one spectral shape, so the guess never misses in the timed
-                               region; here one row is rebuilt so that it has the largest L1 norm but not the tallest
-                               peak and every step has to be repaired (second search + in-place phase rotation)
-      c128                     complex128 storage (the reference's arithmetic, fid.py:136-139), half the voxels"""
+      speculation_miss         the price of a wrong guess: one row gets a late burst (the tallest peak of its dataset,
+                               in samples the guess stage does not read) and every step has to be repaired
+      heterogeneous            the speculative schedule on `--hetero-sets` DISTINCT datasets of the heterogeneous
+                               family (synth_hetero: 1-8 lines per voxel, widths 2-60 Hz, noise-only voxels, a
+                               lipid-like voxel with the largest L1 norm): measured hits / steps, the measured rate
+                               including whatever repairs happened, and the expected rate from the hit rate
+      c128                     complex128 storage (the reference's arithmetic, fid.py:136-139), same voxel count"""
     import time
 
+    x = xs[0]
+    out = outs[0]
     nv = x.shape[0]
     notes = {}
+    ring = lambda n: [xs[k % len(xs)] for k in range(n)]  # noqa: E731
+    alt = lambda n: [outs[k % 2] for k in range(n)]  # noqa: E731
 
     def rate(inputs, outputs, pl, n, spec):
         pipeline.run_stream(inputs[:4], outputs[:4], pl, speculate=spec)
@@ -462,58 +485,120 @@ def footnotes(torch, pipeline, dev, x, t, out, plan, N, args, speculate, main_ms
         return (time.perf_counter() - t0) / n * 1e3, res
 
     k = max(8, min(args.steps, 40))
-    ms, _ = rate([x] * k, [out] * k, plan, k, False)
+    ms, _ = rate(ring(k), [out] * k, plan, k, False)
     notes["value_classic_schedule"] = nv / (ms * 1e-3)
     notes["classic_schedule_ms_per_step"] = ms
     singles = []
-    for _ in range(7):
+    for i in range(7):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pipeline.run_stream([x], [out], plan, speculate=speculate)
+        pipeline.run_stream([xs[i % len(xs)]], [out], plan, speculate=speculate)
         torch.cuda.synchronize()
         singles.append((time.perf_counter() - t0) * 1e3)
     notes["single_dataset_ms"] = float(np.median(singles[2:]))
     notes["single_dataset_spectra_per_s"] = nv / (notes["single_dataset_ms"] * 1e-3)
     if speculate:
-        # forced miss: row 7 = thirty lines of height 1.2 (largest windowed L1 norm; the brightest voxel peaks at 2.0)
+        # forced miss: row 7 = a burst in samples 600...999 (the guess stage reads samples 0...511), the tallest peak
         xm = x.clone()
         tt = torch.from_numpy(np.asarray(t)).to(x.device)
         row = torch.zeros(x.shape[1], dtype=torch.complex128, device=x.device)
-        for j in range(30):  # >= 76 Hz apart (no two lines add up), spacing jittered so that the sum has no period
-            f0 = -2175.0 + 150.0 * j + 37.0 * ((7 * j) % 3 - 1)
-            row += torch.exp(-20.0 * tt) * torch.exp(2j * np.pi * f0 * tt)
-        xm[7] = (1.2 * row).to(x.dtype)
-        ms_miss, res = rate([xm] * 12, [out] * 12, plan, 12, True)
-        ms_hit, _ = rate([x] * 12, [out] * 12, plan, 12, True)
+        lo, hi = min(600, x.shape[1] - 2), min(1000, x.shape[1])
+        row[lo:hi] = 40.0 * torch.exp(2j * np.pi * 650.0 * tt[lo:hi])
+        xm[7] = row.to(x.dtype)
+        ms_miss, res = rate([xm] * 12, alt(12), plan, 12, True)
+        ms_hit, _ = rate([x] * 12, alt(12), plan, 12, True)
         n_rep = sum(r.speculation == "repaired" for r in res)
         notes["speculation_miss"] = {"forced_miss_steps": 12, "repaired": n_rep, "ms_per_step_all_missed": ms_miss,
                                      "ms_per_step_all_hit_same_length": ms_hit,
                                      "miss_penalty_ms": (ms_miss - ms_hit) if n_rep == 12 else None}
         del xm
+        try:
+            notes["heterogeneous"] = hetero_note(torch, pipeline, x, t, outs, plan, args,
+                                                 notes["speculation_miss"]["miss_penalty_ms"])
+        except Exception as e:  # an out-of-memory box must not cost the headline
+            notes["heterogeneous"] = {"error": repr(e)[:200]}
     if args.dtype == "c64":
         try:
-            nv2 = nv // 2
-            x2 = x[:nv2].to(torch.complex128)
-            # as the headline: outputs alternate between two buffers, the pipeline fill is inside the timed steps
-            out2 = [torch.empty((nv2, N), dtype=torch.complex128, device=x.device) for _ in range(2)]
-            plan2 = pipeline.make_plan(x2, t, N, args.lb)
-            trace = []
-            k2 = 40
-            pipeline.run_stream([x2] * 8, [out2[k % 2] for k in range(8)], plan2, speculate=speculate)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pipeline.run_stream([x2] * k2, [out2[k % 2] for k in range(k2)], plan2, speculate=speculate, trace=trace)
-            torch.cuda.synchronize()
-            ms2 = (time.perf_counter() - t0) / k2 * 1e3
-            main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
-            bytes2 = 16 * (x2.shape[1] + N) * nv2
-            notes["c128"] = {"voxels": nv2, "steps": k2, "value": nv2 / (ms2 * 1e-3), "ms_per_step": ms2, "main_kernel_ms": main2,
-                             "main_kernel_frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "end_to_end_roofline_frac": nv2 / (ms2 * 1e-3) * 16 * (x2.shape[1] + N) / 1e9 / HBM_PEAK_GBPS}
-            del x2, out2
+            notes["c128"] = c128_note(torch, pipeline, xs, t, N, args, speculate)
         except Exception as e:  # an out-of-memory box must not cost the headline
             notes["c128"] = {"error": repr(e)[:200]}
     return notes
+
+
+def hetero_note(torch, pipeline, x, t, outs, plan, args, miss_penalty_ms):
+    """Hit rate of the speculative schedule on DISTINCT datasets of the heterogeneous family, in batches of 16
+    resident datasets; every dataset is guessed, searched, transformed and verified once."""
+    import time
+
+    nv, nt = x.shape
+    dt = float(t[1] - t[0])
+    total = max(4, args.hetero_sets)
+    per = min(16, total)
+    hits = repaired = steps = 0
+    wall = 0.0
+    seed = 0
+    while steps < total:
+        n = min(per, total - steps)
+        sets = []
+        for _ in range(n):
+            sets.append(synth_hetero(torch, nv, nt, dt, seed, x.device, x.dtype)[0])
+            seed += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipeline.run_stream(sets, [outs[k % 2] for k in range(n)], plan, speculate=True)
+        torch.cuda.synchronize()
+        wall += time.perf_counter() - t0
+        hits += sum(r.speculation == "hit" for r in res)
+        repaired += sum(r.speculation == "repaired" for r in res)
+        steps += n
+        del sets
+    h = hits / steps
+    ms = wall / steps * 1e3
+    note = {"family": "synth_hetero: 1-8 lines/voxel, widths 2-60 Hz, 5% noise-only voxels, one lipid-like voxel "
+                      "(largest L1 norm), distinct seeds", "datasets": steps, "hit": hits, "repaired": repaired,
+            "hit_rate": h, "ms_per_step_measured": ms, "value_measured": nv / (ms * 1e-3)}
+    if miss_penalty_ms is not None and repaired == 0:
+        note["value_expected_at_hit_rate"] = note["value_measured"]
+    elif miss_penalty_ms is not None:
+        t_hit = ms - (1.0 - h) * miss_penalty_ms
+        note["value_expected_at_hit_rate"] = nv / ((h * t_hit + (1.0 - h) * (t_hit + miss_penalty_ms)) * 1e-3)
+    return note
+
+
+def c128_note(torch, pipeline, xs, t, N, args, speculate):
+    """complex128 storage -- the reference's arithmetic (fid.py:136-139 promotes to complex128) -- on the SAME voxel
+    count as the headline, as a record of its own: rate, main-kernel time by HIP events, roofline fractions (16 B per
+    sample: twice the bytes per spectrum)."""
+    import time
+
+    nv = xs[0].shape[0]
+    k2 = 40
+    x2 = [x.to(torch.complex128) for x in xs[:2]]
+    # as the headline: outputs alternate between two buffers, the pipeline fill is inside the timed steps
+    out2 = [torch.empty((nv, N), dtype=torch.complex128, device=xs[0].device) for _ in range(2)]
+    plan2 = pipeline.make_plan(x2[0], t, N, args.lb)
+    trace = []
+    pipeline.run_stream([x2[k % 2] for k in range(8)], [out2[k % 2] for k in range(8)], plan2, speculate=speculate)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = pipeline.run_stream([x2[k % 2] for k in range(k2)], [out2[k % 2] for k in range(k2)], plan2, speculate=speculate,
+                              trace=trace)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / k2 * 1e3
+    main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
+    bytes2 = 16 * (x2[0].shape[1] + N) * nv
+    hot = (x2[0].shape[1], N) == (4096, 8192)
+    return {"voxels": nv, "steps": k2, "value": nv / (ms2 * 1e-3), "ms_per_step": ms2, "dtype": "f64",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_zf2d<FftPlan<4096,256,16,16,16>, ...>" if hot else "xm_pipeline_fused_ramp main pass")
+                                   + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")"),
+                         "achieved": bytes2 / (main2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes2,
+                         "avg_launch_ms": main2, "traffic": None},
+            "main_kernel_ms": main2, "main_kernel_frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "end_to_end_roofline_frac": nv / (ms2 * 1e-3) * 16 * (x2[0].shape[1] + N) / 1e9 / HBM_PEAK_GBPS,
+            "speculation": ({"hit": sum(r.speculation == "hit" for r in res),
+                             "repaired": sum(r.speculation == "repaired" for r in res)} if speculate else None)}
 
 
 def cpu_baseline(x, t, N, lb, budget_s, nv_full):

@@ -56,7 +56,7 @@ typedef enum {
                                   no per-row outputs.  `argidx` == NULL: the key stays for xm_argmax_key_take (merges,
                                   decodes, clears).  `argidx` != NULL: it points to a result record `xm_argmax_result`, device-accessible --
                                   e.g. pinned host memory -- that the kernel's last workgroup fills itself, clearing the key. */
-#define XM_KEY_BYTES 8192     /* 64 partial keys on cache lines of their own */
+#define XM_KEY_BYTES 65536    /* 64 partial keys on cache lines of their own (8 KiB), then scratch words of the consumers */
 typedef struct {
   float max2;   /* max |X|^2 of the launch                      */
   float pad_;

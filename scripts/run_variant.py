@@ -4,7 +4,8 @@ VARIANT:
   main  = main pass of the classic schedule: k_zf2p mode 9 (write + phase ramp)
   table = write + phase TABLE (k_zf2p mode 3; the first-generation kernel with XM_ZF2_GEN1=1)
   write = write only;  pre = arg-max pre-pass of the classic schedule
-  guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass
+  guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass (round 2)
+  coarse = the guess stage of round 3: xm_guess_rows (coarse spectra, k_zf2p<512-plan, 4, 17>) + xm_guess_refine
   rows  = write + phase ramp + per-row maxima (value only): the complex128 main pass of the speculative schedule
 DTYPE=c128 runs the complex128 kernels (use NV=32768)."""
 import sys, os, torch
@@ -21,12 +22,21 @@ am = torch.empty(nv, device="cuda", dtype=rd); ai = torch.empty(nv, dtype=torch.
 key = dev.new_argmax_key("cuda")
 gmax = torch.empty(1, device="cuda"); gflat = torch.empty(1, dtype=torch.int64, device="cuda")
 ramp = (0.7, 0.0085)
-kw = {"guess": {}, "write": dict(want_out=True), "pre": dict(want_out=False, want_argmax=True, argmax_value_only=True),
+kw = {"guess": {}, "coarse": {}, "write": dict(want_out=True), "pre": dict(want_out=False, want_argmax=True, argmax_value_only=True),
       "table": dict(want_out=True, phase_table=ph), "main": dict(want_out=True, phase_ramp=ramp),
       "all": dict(want_out=True, phase_ramp=ramp, global_key=key),
       "rows": dict(want_out=True, phase_ramp=ramp, want_argmax=True, argmax_value_only=True)}[var]
+est = torch.empty(nv, device="cuda", dtype=torch.float32)
+wkey = dev.new_argmax_key("cuda")
+hflat = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+hmax = torch.zeros(1, dtype=torch.float32, pin_memory=True)
+row = torch.empty((1, nt), dtype=torch.complex128, device="cuda")
+w32 = w.to(torch.float32)
 for _ in range(int(os.environ.get("REPS", 3))):
-    if var == "guess":
+    if var == "coarse":
+        dev.guess_rows(x, N, w32, est, key)
+        dev.guess_refine(x, N, w32, est, key, wkey, hmax, hflat, row)
+    elif var == "guess":
         dev.row_l1(x, w, 0, n_used=2304, sub_step=8, key=key)
         dev.argmax_key_take(key, N, gmax, gflat)
     else:

@@ -19,6 +19,7 @@ struct XmKeyResult {
 };
 
 #define XM_KEY_SLOTS 64
+#define XM_KEY_GBEST_WORD 2048  // 32-bit word of a key buffer behind the 64 partial keys: xm_guess_refine's 64 partial bounds
 #define XM_KEY_STRIDE 16  // 64-bit words between partial keys (128 bytes)
 
 template <class T>
@@ -60,6 +61,7 @@ struct PipeArgs {
   float* est;                         // per-row coarse estimate of max |X|^2: written by the guess pass, read by the refine pass
   unsigned long long* gkey_in;        // refine pass: the guess pass's key -- its maximum sets the candidate threshold
   float band2;                        // ... rows with est >= band2 * max(est) are transformed exactly
+  unsigned* gbest;                    // ... float bits of the best exact max |X|^2 so far: 64 partial bounds, 128 B apart (0 at launch, left 0)
   float* take_max2;                   // refine pass, last workgroup out: max |X|^2 of the winning candidate,
   long long* take_flat;               // ... its row * n, and
   Cx<double>* take_row;               // ... its n_in samples as complex128 (the search's input is recomputed in fp64)

@@ -179,6 +179,7 @@ int xm_zf2p_guess_refine(const void* in, int64_t in_stride, const float* window,
   A.amax_value_only = 1;
   A.scale = scale;
   A.gkey = work_key;
+  A.gbest = reinterpret_cast<unsigned*>(work_key) + XM_KEY_GBEST_WORD;
   A.gkey_in = guess_key;
   A.est = const_cast<float*>(est);
   A.absmax2 = const_cast<float*>(est);  // (the kernel's "maxima wanted" marker)

@@ -33,7 +33,12 @@
 //       ZF2P_CAND -- "refine": every workgroup scans its share of the estimates (rows dealt round-robin with a
 //                    rotation, so neighbouring bright voxels go to different workgroups), transforms its candidates
 //                    exactly (full row, the arithmetic of the main pass) and merges (max |X|^2, row) into a key; the
-//                    last workgroup out decodes the key, clears both keys and gathers the winning FID as complex128;
+//                    last workgroup out decodes the key, clears both keys and gathers the winning FID as complex128.
+//                    Branch and bound: a workgroup keeps its (at most 16) candidates with the LARGEST estimates and
+//                    takes them in descending order; every exact maximum is published (PipeArgs::gbest, atomic max) and
+//                    a candidate whose estimate falls below band^2 x the best exact maximum so far is skipped -- on
+//                    data whose rows are alike (a phantom: thousands of rows inside the band) the second round already
+//                    finds nothing left to do;
 //       ZF2P_IN64 -- rows are complex128 in memory, converted to float on load (ranking statistics for the
 //                    complex128 schedule: the verification against the fp64 main pass stays exact).
 #pragma once
@@ -42,7 +47,7 @@
 enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8, ZF2P_EST = 16, ZF2P_CAND = 32, ZF2P_IN64 = 64 };  // OPT bits
 constexpr int ZF2P_CAND_CAP = 16;      // candidates one workgroup transforms at most
 constexpr int ZF2P_CAND_KMAX = 16384;  // row blocks (of gridDim.x rows each) one workgroup can scan: bits of its LDS bitmap
-constexpr size_t zf2p_cand_lds_bytes() { return (ZF2P_CAND_CAP + 3 + ZF2P_CAND_KMAX / 32) * sizeof(unsigned); }
+constexpr size_t zf2p_cand_lds_bytes() { return (2 * ZF2P_CAND_CAP + 3 + ZF2P_CAND_KMAX / 32) * sizeof(unsigned); }
 
 constexpr int xm_ilog2(int v) {
   int s = 0;
@@ -81,23 +86,83 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   // stage-0 column of this thread
   const unsigned col = L16 ? (t & ~(XM_WAVE - 1u)) + 2u * (lane & 31u) + half : t;
 
+  // rows this workgroup iterates over: all of the launch's (static stride or the queue), or its own candidates
+  long long n_rows = A.n_batch;
+  unsigned* cand = lds_next + 1;
+  const unsigned n_in = (unsigned)A.n_in;
+  if constexpr (CAND) {
+    float* cand_e = reinterpret_cast<float*>(cand + ZF2P_CAND_CAP);  // their estimates, descending
+    unsigned* cand_n = cand + 2 * ZF2P_CAND_CAP;
+    unsigned* top_bits = cand_n + 1;
+    unsigned* bitmap = top_bits + 1;
+    const unsigned G = gridDim.x, b = blockIdx.x;
+    const unsigned kmax = (unsigned)((A.n_batch + G - 1) / G);  // <= ZF2P_CAND_KMAX (checked by the launcher)
+    for (unsigned i = t; i < (kmax + 31u) / 32u; i += NT) bitmap[i] = 0u;
+    if (t < XM_WAVE) {  // the largest estimate of the launch: the high word of the guess pass's key
+      const unsigned long long k = __hip_atomic_load(A.gkey_in + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned hi = wave_reduce_u32<true>((unsigned)(k >> 32));
+      if (t == 0) *top_bits = hi;
+    }
+    __syncthreads();
+    const float thr = A.band2 * __uint_as_float(*top_bits);
+    // row of (workgroup b, block k): k G + (b + 37 k) mod G -- a bijection per block, rotated from block to block
+    for (unsigned k = t; k < kmax; k += NT) {
+      const long long r = (long long)k * G + (b + 37u * k) % G;
+      if (r < A.n_batch) {
+        const float e = A.est[r];
+        if (e >= thr || e != e) atomicOr(&bitmap[k >> 5], 1u << (k & 31u));  // a NaN row is always a candidate
+      }
+    }
+    __syncthreads();
+    if (t == 0) {  // the ZF2P_CAND_CAP largest estimates (a NaN first), descending; equal estimates: the lower row first
+      unsigned n = 0;
+      for (unsigned w = 0; w < (kmax + 31u) / 32u; ++w) {
+        unsigned bits = bitmap[w];
+        while (bits) {
+          const unsigned k = w * 32u + (unsigned)__builtin_ctz(bits);
+          bits &= bits - 1u;
+          const unsigned r = (unsigned)((long long)k * G + (b + 37u * k) % G);
+          float e = A.est[r];
+          e = e != e ? __builtin_inff() : e;
+          unsigned pos = n;  // insertion point: behind everything >= e (rows arrive in ascending order)
+          while (pos > 0 && cand_e[pos - 1] < e) --pos;
+          if (pos >= (unsigned)ZF2P_CAND_CAP) continue;
+          const unsigned top = n < (unsigned)ZF2P_CAND_CAP ? n : (unsigned)ZF2P_CAND_CAP - 1u;
+          for (unsigned i = top; i > pos; --i) {
+            cand[i] = cand[i - 1];
+            cand_e[i] = cand_e[i - 1];
+          }
+          cand[pos] = r;
+          cand_e[pos] = e;
+          n = n < (unsigned)ZF2P_CAND_CAP ? n + 1u : n;
+        }
+      }
+      *cand_n = n;
+    }
+    __syncthreads();
+    n_rows = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*cand_n);
+  }
+  // a workgroup without candidates skips the table loads (it still counts itself out at the end)
+  const bool live = !CAND || n_rows > 0;
+
   HT tw;
   tw.mid = HT::mid_in_lds() ? mid : A.tw;
-  tw.load(A.tw, (int)t);
-  for (unsigned i = t; i < (unsigned)HT::mid_lds_size(); i += NT) mid[i] = A.tw[i];
+  if (live) {
+    tw.load(A.tw, (int)t);
+    for (unsigned i = t; i < (unsigned)HT::mid_lds_size(); i += NT) mid[i] = A.tw[i];
+  }
   if constexpr (RAMP) {  // per-thread part of the output phase, e^{i b 2t}, folded into the last-stage twiddles
     double sn, cs;
     sincos(A.ramp_db * (double)(2u * t), &sn, &cs);
     tw.fold(mk<T>((T)cs, (T)sn));
   }
-  Cx<T> rot = A.aux[col];  // W_N^col
+  Cx<T> rot = live ? A.aux[col] : mk<T>(T(0), T(0));  // W_N^col
   if constexpr (RAMP) rot = rot * mk<T>(A.ramp_e[0], A.ramp_e[1]);  // odd bins: e^{i b (k + 1)} = e^{i b k} e^{i b}
-  const unsigned n_in = (unsigned)A.n_in;
   const unsigned coff = col - (unsigned)A.pad_left;  // wraps for col < pad_left -> fails the range test
   T w[P];  // window sample * FFT scale; 0 outside the acquired samples (the zero fill)
 #pragma unroll
   for (int q = 0; q < P; ++q) {
-    const bool ok = (coff + NT * q) < n_in;
+    const bool ok = live && (coff + NT * q) < n_in;
     w[q] = ok ? (A.window ? A.window[col + NT * q] * A.scale : A.scale) : T(0);
   }
   __syncthreads();
@@ -130,50 +195,23 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   // first row (np.argmax of zeros is 0; a key of value 0 is non-zero through its row word)
   unsigned best_key = 0, best_row = 0;
   bool have = false;
-  // rows this workgroup iterates over: all of the launch's (static stride or the queue), or its own candidates
-  long long n_rows = A.n_batch;
-  unsigned* cand = lds_next + 1;
-  if constexpr (CAND) {
-    unsigned* cand_n = cand + ZF2P_CAND_CAP;
-    unsigned* top_bits = cand_n + 1;
-    unsigned* bitmap = top_bits + 1;
-    const unsigned G = gridDim.x, b = blockIdx.x;
-    const unsigned kmax = (unsigned)((A.n_batch + G - 1) / G);  // <= ZF2P_CAND_KMAX (checked by the launcher)
-    for (unsigned i = t; i < (kmax + 31u) / 32u; i += NT) bitmap[i] = 0u;
-    if (t < XM_WAVE) {  // the largest estimate of the launch: the high word of the guess pass's key
-      const unsigned long long k = __hip_atomic_load(A.gkey_in + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned hi = wave_reduce_u32<true>((unsigned)(k >> 32));
-      if (t == 0) *top_bits = hi;
-    }
-    __syncthreads();
-    const float thr = A.band2 * __uint_as_float(*top_bits);
-    // row of (workgroup b, block k): k G + (b + 37 k) mod G -- a bijection per block, rotated from block to block
-    for (unsigned k = t; k < kmax; k += NT) {
-      const long long r = (long long)k * G + (b + 37u * k) % G;
-      if (r < A.n_batch) {
-        const float e = A.est[r];
-        if (e >= thr || e != e) atomicOr(&bitmap[k >> 5], 1u << (k & 31u));  // a NaN row is always a candidate
-      }
-    }
-    __syncthreads();
-    if (t == 0) {  // ascending rows, at most ZF2P_CAND_CAP of them
-      unsigned n = 0;
-      for (unsigned w = 0; w < (kmax + 31u) / 32u && n < (unsigned)ZF2P_CAND_CAP; ++w) {
-        unsigned bits = bitmap[w];
-        while (bits && n < (unsigned)ZF2P_CAND_CAP) {
-          const unsigned k = w * 32u + (unsigned)__builtin_ctz(bits);
-          bits &= bits - 1u;
-          cand[n++] = (unsigned)((long long)k * G + (b + 37u * k) % G);
-        }
-      }
-      *cand_n = n;
-    }
-    __syncthreads();
-    n_rows = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*cand_n);
-  }
   auto rowid = [&](long long v) -> long long {  // iteration index -> row of the batch
     if constexpr (CAND) return (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)cand[v]);
     else return v;
+  };
+  unsigned gb_seen = 0;  // the best exact maximum (float bits) this wave has read so far
+  // CAND: the first candidate at or behind v that the best exact maximum found so far (by any workgroup) does not rule out
+  auto next_live = [&](long long v) -> long long {
+    if constexpr (CAND) {
+      const float* cand_e = reinterpret_cast<const float*>(cand + ZF2P_CAND_CAP);
+      // (64 partial bounds on cache lines of their own, like the keys: one address takes ~90 atomics per microsecond)
+      const unsigned gb = wave_reduce_u32<true>(__hip_atomic_load(A.gbest + lane * (2u * XM_KEY_STRIDE), __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT));
+      gb_seen = gb;
+      const float lim = A.band2 * __uint_as_float(gb);  // NaN (a NaN row was found): nothing is ruled out
+      while (v < n_rows && __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cand_e[v]))) < lim) ++v;
+    }
+    return v;
   };
   // Work is handed out in CHUNKS of `ch` consecutive rows (one ticket per chunk: a single counter takes ~90 tickets
   // per microsecond, short rows would outrun it).  c_cur = the chunk being transformed, c_nxt = the one after it
@@ -193,7 +231,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
 
   while (s < n_rows) {
     const bool chunk_end = (off + 1 == (unsigned)ch) || (s + 1 >= n_rows);
-    const long long s_nxt = chunk_end ? c_nxt * ch : s + 1;  // the row prefetched during this transform
+    // the row prefetched during this transform.  CAND: no prefetch -- the successor is chosen late in the transform (the
+    // bound is fresher then), by the first wave for the whole workgroup, and handed over through LDS like a queue ticket
+    long long s_nxt = chunk_end ? c_nxt * ch : s + 1;
     // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in ~100 hoisted registers
     unsigned tt = t, cc = col, sh = (unsigned)A.out_shift, nin = n_in, pl = (unsigned)A.pad_left, ee0 = e0;
     asm volatile("" : "+v"(tt));
@@ -235,8 +275,19 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       v[q].re = V{e.re, o.re};
       v[q].im = V{e.im, o.im};
     });
-    if (s_nxt < n_rows) fetch(rowid(s_nxt), ee0, cc - pl, nin);
-    if constexpr (QUEUE) {
+    if constexpr (!CAND) {
+      if (s_nxt < n_rows) fetch(rowid(s_nxt), ee0, cc - pl, nin);
+    }
+    if constexpr (CAND) {
+      FFT::run_cols(v, lds, tw, (int)tt, (int)cc, [&]() {
+        if (tt < XM_WAVE) {
+          const long long nx = next_live(s + 1);
+          if (tt == 0u) *lds_next = (unsigned)nx;
+        }
+      });
+      s_nxt = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*lds_next);
+      if (s_nxt < n_rows) fetch(rowid(s_nxt), ee0, cc - pl, nin);  // (lands while the maxima are reduced)
+    } else if constexpr (QUEUE) {
       // first row of a chunk: thread 0 claims the chunk after next right after the prefetch is issued; the ticket
       // is back by the last exchange and goes through LDS in front of one of the transform's own barriers
       const bool claim = off == 0u;  // workgroup-uniform
@@ -265,7 +316,12 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         const unsigned key = wave_reduce_u32<true>(__float_as_uint(bv));
         if (A.gkey) {  // rows come in ascending order: strict > keeps the lowest row among equal values
           const unsigned r = (unsigned)rowid(s);
-          const bool take = !have || key > best_key;
+          // (candidates come in descending order of their ESTIMATES: equal maxima -> the lower row, explicitly)
+          const bool take = !have || key > best_key || (CAND && key == best_key && r < best_row);
+          if constexpr (CAND) {
+            // a lower bound of this row's maximum: rules out weaker candidates (published only when it raises the bound)
+            if (lane == 0u && key > gb_seen) atomicMax(A.gbest + (blockIdx.x % XM_KEY_SLOTS) * (2u * XM_KEY_STRIDE), key);
+          }
           best_key = take ? key : best_key;
           best_row = take ? r : best_row;
           have = true;
@@ -366,8 +422,10 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
         if (last) {
           unsigned long long k = __hip_atomic_load(A.gkey + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(A.gkey + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if constexpr (CAND)  // every workgroup has read the guess pass's key by now
+          if constexpr (CAND) {  // every workgroup has read the guess pass's key by now
             __hip_atomic_store(A.gkey_in + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.gbest + t * (2u * XM_KEY_STRIDE), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
 #pragma unroll
           for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
             const unsigned hi = (unsigned)__shfl_xor((int)(k >> 32), m, XM_WAVE), lo = (unsigned)__shfl_xor((int)(unsigned)k, m, XM_WAVE);

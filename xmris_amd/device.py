@@ -439,7 +439,7 @@ def guess_refine(x2, n_out: int, window32, est, guess_key, work_key, gmax, gflat
 
 def new_argmax_key(device):
     """A zeroed arg-max key buffer (XM_KEY_BYTES) for `row_l1(key=)` / `pipeline_fused(global_key=)`."""
-    return _torch().zeros(8192 // 8, dtype=_torch().int64, device=device)
+    return _torch().zeros(65536 // 8, dtype=_torch().int64, device=device)
 
 
 def new_key_result():

@@ -422,7 +422,19 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # guess stage: coarse spectra + exact check of the candidates (both precisions); else the windowed L1 norm's winner
     use_guess = (os.environ.get("XM_GUESS_L1") is None and plan.window is not None
                  and all(dev.guess_supported(x, plan.n_out, plan.pad_left) for x in distinct))
-    band = float(os.environ.get("XM_GUESS_BAND", "0.75"))
+    # Candidate band of the guess stage.  A coarse spectrum (first 512 samples, 1024 bins) underestimates a line's height
+    # by the part of its windowed FID beyond sample 512 -- at most the window's own weight out there, for a line that
+    # does not decay by itself -- and by the grid's scalloping (>= 0.9 for a 2x zero-filled truncated line): rows whose
+    # estimate reaches 0.9 x (window weight inside the first 512 samples) of the largest estimate are checked exactly
+    # (lb = 5 Hz at 5 kHz: 0.72; measured on the heterogeneous family: estimates within [0.83, 0.97] of the true peaks,
+    # scripts/study_guess_statistics.py).  A wider band only costs exact transforms (<= 16 per workgroup).
+    band = plan.extra.get("guess_band")
+    if band is None:
+        wabs = np.abs(np.asarray(plan.window_host, dtype=np.float64)[plan.pad_left:plan.pad_left + plan.n_in])
+        inside = float(wabs[:512].sum()) / max(float(wabs.sum()), 1e-300)
+        band = plan.extra["guess_band"] = float(min(0.95, max(0.25, 0.9 * inside)))
+    if os.environ.get("XM_GUESS_BAND"):  # tuning switch
+        band = float(os.environ["XM_GUESS_BAND"])
     key = ("spec_bufs", nb, str(rd), ring, use_guess)
     bufs = plan.extra.get(key)
     if bufs is None:
@@ -474,7 +486,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             pool = plan.extra[("search_pool", n_workers)] = ThreadPoolExecutor(max_workers=n_workers,
                                                                               thread_name_prefix="xm-search")
 
-    def guess(j):  # streaming L1 norms + the selection stage on the row with the largest one
+    def guess(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
         b = j % ring
         ev = events[j]
         if trace is not None:
