@@ -56,12 +56,16 @@ typedef enum {
                                   no per-row outputs.  `argidx` == NULL: the key stays for xm_argmax_key_take (merges,
                                   decodes, clears).  `argidx` != NULL: it points to a result record `xm_argmax_result`, device-accessible --
                                   e.g. pinned host memory -- that the kernel's last workgroup fills itself, clearing the key. */
-#define XM_KEY_BYTES 65536    /* 64 partial keys on cache lines of their own (8 KiB), then scratch words of the consumers */
+#define XM_KEY_BYTES 131072   /* 64 partial keys on cache lines of their own (8 KiB), scratch words of the consumers, and from
+                                 byte 65536 the per-wave (value, row) slots of the complex128 kernels */
 typedef struct {
-  float max2;   /* max |X|^2 of the launch                      */
+  float max2;   /* max |X|^2 of the launch (XM_C128: these eight bytes hold it as a double) */
   float pad_;
   int64_t flat; /* winning row * n_out (index along the axis: 0) */
 } xm_argmax_result;
+/* XM_C128 takes XM_AMAX_GLOBAL_KEY on the geometries of xm_pipeline_key_native (half lengths 4096 and 8192) and only with a
+ * result record: 64 bits of value + a row do not fit one atomic, so every wave leaves its (value, row) pair in a slot
+ * of the key buffer and the last workgroup out merges them; the key buffer needs no clearing. */
 
 int xm_version(void); /* 10000*major + 100*minor + patch */
 const char* xm_last_error_string(void);
@@ -84,6 +88,10 @@ int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, i
 
 /* A3/A4/A5  fft / ifft / fftshift folded  (processing/fourier.py:153, 210, 31, 57).
  * out[b, (m + s_out) mod n] = scale * sum_k in[b, (k - s_in) mod n] * e^{-+2 pi i k m / n}. */
+/* 1 when xm_pipeline_fused(_ramp) accepts XM_AMAX_GLOBAL_KEY for this geometry and dtype, else 0. */
+int xm_pipeline_key_native(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags,
+                           int dtype);
+
 int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype,
                      void* stream);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "xm_pipeline_fused": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
     "xm_pipeline_fused_ramp": (_i, [_p, _l, _p, _p, ctypes.c_double, ctypes.c_double, _l, _i, _i, _i, _u, _p, _p, _i, _p]),
     "xm_pipeline_ramp_native": (_i, [_p, _l, _i, _i, _i, _u, _i]),
+    "xm_pipeline_key_native": (_i, [_p, _l, _i, _i, _i, _u, _i]),
     "xm_row_l1": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "xm_argmax_key_take": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _i, _p]),
     "xm_guess_supported": (_i, [_p, _l, _i, _i, _i, _u, _i]),

@@ -100,15 +100,22 @@ def default_threads() -> int:
     except (OSError, ValueError):
         pass
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    if local_world > 1:
+        # Several ranks on one node share its cores.  Searches are per DATASET, not per rank: only the rank that owns
+        # a dataset's winning spectrum searches, the streaming executor keeps two searches in flight on the whole node
+        # (`pipeline._run_stream_speculative`: look-ahead 2 with an exchange), and the other ranks wait for the
+        # broadcast sleep-polling.  So the node-wide budget is what the ranks' launch threads leave: one core per rank
+        # is reserved for launching and polling (a launch thread is busy for ~0.2 ms of a 1.2 ms step), the searches
+        # in flight share the rest -- 16 CPUs and 8 ranks: 8 cores, 4 per search (1.1 ms of generations; round 2's
+        # (cpus - 2 ranks) / 2 left ONE thread there: 3.2 ms against a 1.2 ms device period).  Any team size works (a
+        # batch of evaluations is cut into 16+ work units).
+        return max(1, min(16, cpus - local_world))
     # Half of the share, as a power of two (the work units of a batch are 4 evaluations x 4 parts): a team that
     # fills the whole CPU quota while it spins leaves no headroom for the HIP runtime's threads, and a cgroup that
     # overdraws its quota is frozen until the next 100 ms period -- measured as rare 15-25 ms stalls of the whole
     # pipeline with 16 threads on a 16-CPU share, none with 8 (the search takes 0.95 instead of 0.71 ms, still
     # hidden behind the device).
-    # Several ranks on one node: only the rank that OWNS a dataset's winning spectrum searches (the others wait,
-    # sleep-polling, for the broadcast), so the team is not divided by the number of ranks -- two cores per rank stay
-    # reserved for launching and polling, the owner's searches may take half of the rest.
-    share = max(1, cpus // 2) if local_world == 1 else max(1, (cpus - 2 * local_world) // 2)
+    share = max(1, cpus // 2)
     team = 1
     while team * 2 <= min(16, share):
         team *= 2

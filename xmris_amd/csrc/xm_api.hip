@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -513,9 +514,11 @@ static int pipeline_common(const void* in, int64_t in_row_stride, void* out, con
   if (n_in < 1 || pad_left < 0 || pad_left + n_in > n_out || in_row_stride < n_in)
     return fail(XM_ERR_INVALID_ARG, "pipeline: bad zero-fill geometry or row stride");
   if (flags & XM_AMAX_GLOBAL_KEY) {
-    if (!absmax2 || n_batch > 0xffffffffLL || dtype != XM_C64 ||
-        !xm_pipeline_ramp_native(in, in_row_stride, n_in, n_out, pad_left, flags & ~(XM_AMAX_GLOBAL_KEY | XM_AMAX_VALUE_ONLY), dtype))
-      return fail(XM_ERR_INVALID_ARG, "pipeline: XM_AMAX_GLOBAL_KEY needs a key, complex64 and a geometry of xm_pipeline_ramp_native");
+    if (!absmax2 || n_batch > 0xffffffffLL ||
+        !xm_pipeline_key_native(in, in_row_stride, n_in, n_out, pad_left, flags & ~(XM_AMAX_GLOBAL_KEY | XM_AMAX_VALUE_ONLY), dtype))
+      return fail(XM_ERR_INVALID_ARG, "pipeline: XM_AMAX_GLOBAL_KEY needs a key and a geometry of xm_pipeline_key_native");
+    if (dtype == XM_C128 && !argidx)
+      return fail(XM_ERR_INVALID_ARG, "pipeline: complex128 arg-max keys are decoded by the launch itself (result record needed)");
   } else if ((absmax2 == nullptr) != (argidx == nullptr))
     return fail(XM_ERR_INVALID_ARG, "pipeline: absmax2 and argidx must be given together");
   if (!out && !absmax2) return fail(XM_ERR_INVALID_ARG, "pipeline: nothing to produce");
@@ -554,6 +557,14 @@ int xm_pipeline_ramp_native(const void* in, int64_t in_row_stride, int n_in, int
   if ((dtype != XM_C64 && dtype != XM_C128) || n_in < 1 || pad_left < 0 || pad_left + n_in > n_out) return 0;
   return dtype == XM_C64 ? xm_ramp_native_f32(in, in_row_stride, n_in, n_out, pad_left, flags)
                          : xm_ramp_native_f64(in, in_row_stride, n_in, n_out, pad_left, flags);
+}
+
+int xm_pipeline_key_native(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags,
+                           int dtype) {
+  if (!xm_pipeline_ramp_native(in, in_row_stride, n_in, n_out, pad_left, flags, dtype)) return 0;
+  if (dtype == XM_C64) return 1;
+  static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // (tuning switch: k_zf2<double> has no key)
+  return !gen1 && (n_out == 8192 || n_out == 16384);  // k_zf2d's half lengths
 }
 
 int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype, void* stream) {

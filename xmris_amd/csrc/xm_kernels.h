@@ -19,6 +19,7 @@ struct XmKeyResult {
 };
 
 #define XM_KEY_SLOTS 64
+#define XM_KEY_C128_WORD 8192  // 64-bit word of a key buffer where the complex128 kernels keep their per-wave (value, row) slots
 #define XM_KEY_GBEST_WORD 2048  // 32-bit word of a key buffer behind the 64 partial keys: xm_guess_refine's 64 partial bounds
 #define XM_KEY_STRIDE 16  // 64-bit words between partial keys (128 bytes)
 
@@ -109,6 +110,15 @@ XM_DEV unsigned wave_reduce_u32(unsigned v) {
   v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_BCAST15, 0xa, 0xf, false));
   v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, XM_DPP_BCAST31, 0xc, 0xf, false));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// wave-wide maximum of a 64-bit unsigned key (the bit pattern of a non-negative double, or of a NaN, which outranks
+// every number): the high words first, then the low words of the lanes that hold the largest high word
+XM_DEV unsigned long long wave_reduce_u64_max(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_reduce_u32<true>(hi);
+  const unsigned ml = wave_reduce_u32<true>(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
 }
 
 // (max value, first index) over the 64 lanes of a wave; result uniform across the wave
@@ -384,7 +394,9 @@ XM_DEV void static_for(F&& f) {
 // ZF2_RAMP (with ZF2_WRITE, instead of ZF2_PHASE): the output phase is a linear ramp given in factorised form
 // (PipeArgs::ramp_*), see xm_zf2p.h.  ZF2_PAIR (complex128): both half transforms ride through ONE pass of the
 // block FFT as a two-lane element (32-byte exchange elements, half the barriers) instead of one after the other.
-enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4, ZF2_RAMP = 8, ZF2_VALUE_ONLY = 16, ZF2_PAIR = 32 };
+enum { ZF2_WRITE = 1, ZF2_PHASE = 2, ZF2_AMAX = 4, ZF2_RAMP = 8, ZF2_VALUE_ONLY = 16, ZF2_PAIR = 32,
+       ZF2_GKEY = 64,    // k_zf2d: the maxima go into the launch's arg-max key (PipeArgs::gkey) instead of per-row arrays
+       ZF2_DMA = 128 };  // k_zf2d: the next row is prefetched into the idle exchange buffer (global_load_lds, no registers)
 template <class T, int MODE>
 constexpr bool zf2_paired() {
   return sizeof(T) == 4 || (MODE & ZF2_PAIR) != 0;

@@ -36,10 +36,17 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   return XM_OK;
 }
 
+template <class PL, int MODE>
+int launch_mode_dma(const PipeArgs<T>& A, hipStream_t st) {
+  static const bool no_dma = getenv("XM_ZF2D_NODMA") != nullptr;  // tuning switch: the next row is not prefetched
+  return no_dma ? launch_mode<PL, MODE>(A, st) : launch_mode<PL, MODE | ZF2_DMA>(A, st);
+}
+
 template <class PL>
 int launch_plan(PipeArgs<double> A, const double* ramp, hipStream_t st) {
-  const bool wr = A.out != nullptr, am = A.absmax2 != nullptr;
-  if (!wr) return launch_mode<PL, ZF2_AMAX | ZF2_VALUE_ONLY>(A, st);
+  const bool wr = A.out != nullptr, am = A.absmax2 != nullptr, key = A.gkey != nullptr;
+  constexpr int AM = ZF2_AMAX | ZF2_VALUE_ONLY, AMK = AM | ZF2_GKEY;
+  if (!wr) return key ? launch_mode_dma<PL, AMK>(A, st) : launch_mode_dma<PL, AM>(A, st);
   if (ramp) {
     // e^{i (a + b k)}, k = base_q + 2t (+1): the wave-uniform factors, and e^{i b} for the odd bins (xm_zf2p.h)
     constexpr unsigned N = 2 * PL::N;
@@ -52,9 +59,11 @@ int launch_plan(PipeArgs<double> A, const double* ramp, hipStream_t st) {
     A.ramp_e[0] = std::cos(ramp[1]);
     A.ramp_e[1] = std::sin(ramp[1]);
     A.ramp_db = ramp[1];
-    return am ? launch_mode<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<PL, ZF2_WRITE | ZF2_RAMP>(A, st);
+    if (key) return launch_mode_dma<PL, ZF2_WRITE | ZF2_RAMP | AMK>(A, st);
+    return am ? launch_mode_dma<PL, ZF2_WRITE | ZF2_RAMP | AM>(A, st) : launch_mode_dma<PL, ZF2_WRITE | ZF2_RAMP>(A, st);
   }
-  return am ? launch_mode<PL, ZF2_WRITE | ZF2_AMAX | ZF2_VALUE_ONLY>(A, st) : launch_mode<PL, ZF2_WRITE>(A, st);
+  if (key) return launch_mode_dma<PL, ZF2_WRITE | AMK>(A, st);
+  return am ? launch_mode_dma<PL, ZF2_WRITE | AM>(A, st) : launch_mode_dma<PL, ZF2_WRITE>(A, st);
 }
 
 }  // namespace

@@ -183,7 +183,10 @@ int xm_solver_de(void* h, int p0_only, unsigned seed, double tol, int maxiter, d
     MT19937 rng_before;
     int ridx_before[30];
   };
-  const int batch_max = std::max(1, std::min(M, xm_solver_get_batch(h)));
+  // (a serial search gains nothing from evaluating ahead: every discarded trial is wasted time; two threads look one
+  // trial ahead.  The committed sequence is the same for every batch size.)
+  const int team = xm_solver_get_threads(h);
+  const int batch_max = std::max(1, std::min(M, team <= 1 ? 1 : (team == 2 ? 2 : xm_solver_get_batch(h))));
   std::vector<Spec> spec(batch_max);
   std::vector<double> ps(2 * batch_max, 0.0), es(batch_max);
   std::vector<char> mod(M);

@@ -108,6 +108,15 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
   constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, RAMP = (MODE & ZF2_RAMP) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
   static_assert((WRITE || AMAX) && !(MODE & ZF2_PHASE) && (WRITE || !RAMP), "no phase table; a ramp needs an output");
   static_assert(!AMAX || (MODE & ZF2_VALUE_ONLY), "maxima: value only");
+  constexpr bool GKEY = (MODE & ZF2_GKEY) != 0;
+  // ZF2_DMA: the next row's samples are prefetched by the memory system itself -- `global_load_lds_dwordx4`, no
+  // destination registers -- into the exchange buffer, which is idle from the last exchange of the second transform
+  // until the first one of the next row: the loads are in flight during the epilogue (maxima + stores).  Sample
+  // t + NT q of the row lands at byte 16 (NT q + t): every thread reads back exactly what its own lane fetched, so only
+  // the counter wait is needed -- and ONE extra barrier per row, between the last thread's read of its staged samples
+  // and the first stage-0 scatter into the same bytes.
+  constexpr bool DMA = (MODE & ZF2_DMA) != 0;
+  static_assert(!GKEY || AMAX, "the key holds maxima");
   using FFT = BlockFFT<T, PL>;
   // one last-stage butterfly per thread: generated twiddles; P/2 radix-2 ones: one twiddle + compile-time rotations
   using TW = typename std::conditional<P == PL::radix(PL::K - 1), ChainTw<T, PL, RAMP>, RotTw<T, PL, RAMP>>::type;
@@ -142,6 +151,13 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
   __syncthreads();
 
   constexpr unsigned CB = sizeof(Cx<T>);
+  // XM_AMAX_GLOBAL_KEY: this wave's best (max |X|^2 bits, row) over the rows its workgroup transforms; rows come in
+  // ascending order (the queue's tickets do), so a strict > keeps the lowest row among equal maxima.  64 bits of
+  // value + a row do not fit one atomic: every wave leaves its pair in a slot of its own and the last workgroup out
+  // merges the slots (below).
+  unsigned long long best_bits = 0;
+  unsigned best_row = 0;
+  bool have = false;
   WorkQueue wq;
   wq.init(A.queue, A.queue_chunk, wq_slot, A.n_batch, t);
   Cx<T> xr[P];
@@ -158,6 +174,21 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
       for (int q = 0; q < P; ++q) xr[q] = row[min(toff2 + NT * q, nin - 1u)];
     }
   };
+  // ZF2_DMA: row s2 -> the staging bytes of the exchange buffer
+  auto stage_row = [&](long long s2, unsigned tt, unsigned nin, unsigned pl) {
+    const Cx<T>* __restrict__ row = A.in + s2 * A.in_stride;
+    char* stage = reinterpret_cast<char*>(lds) + (tt & ~(XM_WAVE - 1u)) * CB;  // wave-uniform; + lane * 16 by the hardware
+    const unsigned toff2 = tt - pl;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const Cx<T>* src = row + ((nin == NT * P && pl == 0u) ? (tt + NT * q) : min(toff2 + NT * q, nin - 1u));
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(stage + (size_t)q * NT * CB), 16, 0, 0);
+    }
+  };
+  if constexpr (DMA) {
+    if (wq.item < A.n_batch) stage_row(wq.item, t, n_in, (unsigned)A.pad_left);
+  }
   for (; wq.item < A.n_batch; wq.advance()) {
     const long long s = wq.item;
     // opaque copies: keep the (loop-invariant) address arithmetic inside the loop instead of in hoisted registers
@@ -166,7 +197,18 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
     asm volatile("" : "+s"(sh));
     asm volatile("" : "+s"(nin));
     asm volatile("" : "+s"(pl));
-    fetch(s, tt, nin, pl);
+    if constexpr (DMA) {
+      // the compiler does not tie the LDS reads below to the global_load_lds that filled the bytes: wait for the
+      // counter explicitly (this also drains the previous row's stores -- as the first load-dependent instruction of
+      // the variant without the prefetch does, the counter returns in order)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const Cx<T>* st = lds + tt;  // (staged: plain layout, no pads)
+#pragma unroll
+      for (int q = 0; q < P; ++q) xr[q] = st[NT * q];
+      __syncthreads();
+    } else {
+      fetch(s, tt, nin, pl);
+    }
     const unsigned ticket = wq.claim(tt);  // the chunk after next; back long before the second transform's hook
 
     Cx<T> e[P], h[P];
@@ -184,6 +226,10 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
     });
     FFT::run_cols(h, lds, tw, (int)tt, (int)tt, [&]() { wq.publish(tt, ticket); });  // odd bins: FFT_H(z W_N^k)
     wq.collect();
+    if constexpr (DMA) {  // the exchange buffer is idle now: the next row streams into it during the epilogue
+      const long long s_nxt = wq.next_item();
+      if (s_nxt < A.n_batch) stage_row(s_nxt, tt, nin, pl);
+    }
 
     const unsigned t2 = 2u * tt;
     if constexpr (AMAX) {
@@ -193,7 +239,15 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
         bv = fmax(bv, h[q].re * h[q].re + h[q].im * h[q].im);
       }
       bv = amax_nan_if_unset(bv);
-      amax_reduce_store<T, (int)NT>(bv, 0, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+      if constexpr (GKEY) {
+        const unsigned long long kb = wave_reduce_u64_max((unsigned long long)__double_as_longlong(bv));
+        const bool take = !have || kb > best_bits;
+        best_bits = take ? kb : best_bits;
+        best_row = take ? (unsigned)s : best_row;
+        have = true;
+      } else {
+        amax_reduce_store<T, (int)NT>(bv, 0, (int)tt, true, s, A.absmax2, A.argidx, red_v, red_i);
+      }
     }
     if constexpr (WRITE) {
       Cx<T>* __restrict__ orow = A.out + s * (long long)N;
@@ -215,6 +269,68 @@ __global__ __launch_bounds__(PL::NT, (zf2d_waves<PL>())) void k_zf2d(PipeArgs<do
         }
         buf_store(rout, t2 * CB, o);
       });
+    }
+  }
+  if constexpr (GKEY) {
+    {
+      constexpr unsigned NW = NT / XM_WAVE;
+      unsigned long long* slots = A.gkey + XM_KEY_C128_WORD;
+      if ((t & (XM_WAVE - 1u)) == 0u) {  // (an idle wave leaves an empty slot: row = all ones loses every tie)
+        unsigned long long* sl = slots + 2u * (blockIdx.x * NW + t / XM_WAVE);
+        __hip_atomic_store(sl, have ? best_bits : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sl + 1, have ? (unsigned long long)best_row : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // every wave's slot is acknowledged (vmcnt) before its workgroup counts itself out: the last one out sees them all
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const unsigned d = atomicAdd(A.queue + 1, 1u);
+        const unsigned last = d == gridDim.x - 1u;
+        if (last) {
+          __hip_atomic_store(A.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(A.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *wq_slot = last;
+      }
+      __syncthreads();
+      if (*wq_slot != 0u && A.key_result) {  // the last workgroup out: merge gridDim.x * NW slots
+        unsigned long long bb = 0, br = ~0ull;
+        for (unsigned i = t; i < gridDim.x * NW; i += NT) {
+          const unsigned long long vb = __hip_atomic_load(slots + 2u * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long vr = __hip_atomic_load(slots + 2u * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool take = vb > bb || (vb == bb && vr < br);
+          bb = take ? vb : bb;
+          br = take ? vr : br;
+        }
+#pragma unroll
+        for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
+          const unsigned long long ob = ((unsigned long long)(unsigned)__shfl_xor((int)(bb >> 32), m, XM_WAVE) << 32) |
+                                        (unsigned)__shfl_xor((int)(unsigned)bb, m, XM_WAVE);
+          const unsigned long long orr = ((unsigned long long)(unsigned)__shfl_xor((int)(br >> 32), m, XM_WAVE) << 32) |
+                                         (unsigned)__shfl_xor((int)(unsigned)br, m, XM_WAVE);
+          const bool take = ob > bb || (ob == bb && orr < br);
+          bb = take ? ob : bb;
+          br = take ? orr : br;
+        }
+        unsigned long long* part = reinterpret_cast<unsigned long long*>(lds);  // (the exchange buffer is idle)
+        if ((t & (XM_WAVE - 1u)) == 0u) {
+          part[2u * (t / XM_WAVE)] = bb;
+          part[2u * (t / XM_WAVE) + 1] = br;
+        }
+        __syncthreads();
+        if (t == 0) {
+          for (unsigned w = 1; w < NW; ++w) {
+            const unsigned long long ob = part[2u * w], orr = part[2u * w + 1];
+            const bool take = ob > bb || (ob == bb && orr < br);
+            bb = take ? ob : bb;
+            br = take ? orr : br;
+          }
+          const long long row = br == ~0ull ? 0 : (long long)br;  // nothing published: row 0
+          *reinterpret_cast<double*>(A.key_result) = __longlong_as_double((long long)bb);  // (XM_C128: max2 as a double)
+          A.key_result->flat = row * (long long)N;
+        }
+      }
+      return;
     }
   }
   wq.finish(t);

@@ -327,6 +327,15 @@ def ramp_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho
                                                     flags, _dtype_code(x2)))
 
 
+def key_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho: bool = True) -> bool:
+    """True when `pipeline_fused(global_key=, key_result=)` is available for this geometry and dtype (complex64: the
+    geometries of `ramp_native`; complex128: half lengths 4096 and 8192)."""
+    _require_device(x2)
+    flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
+    return bool(_lib.load().xm_pipeline_key_native(x2.data_ptr(), x2.shape[1], x2.shape[1], int(n_out), int(pad_left),
+                                                   flags, _dtype_code(x2)))
+
+
 def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
                    ortho: bool = True, want_out: bool = True, want_argmax: bool = False, out=None,
                    absmax2=None, argidx=None, argmax_value_only: bool = False, phase_ramp=None, global_key=None,
@@ -439,7 +448,7 @@ def guess_refine(x2, n_out: int, window32, est, guess_key, work_key, gmax, gflat
 
 def new_argmax_key(device):
     """A zeroed arg-max key buffer (XM_KEY_BYTES) for `row_l1(key=)` / `pipeline_fused(global_key=)`."""
-    return _torch().zeros(65536 // 8, dtype=_torch().int64, device=device)
+    return _torch().zeros(131072 // 8, dtype=_torch().int64, device=device)
 
 
 def new_key_result():
@@ -447,9 +456,11 @@ def new_key_result():
     return _torch().zeros(2, dtype=_torch().int64, pin_memory=True)
 
 
-def read_key_result(rec):
-    """(max |X|^2, flat index) of a `new_key_result` record (after the producing launch has completed)."""
-    return float(rec.view(_torch().float32)[0].item()), int(rec[1].item())
+def read_key_result(rec, complex128: bool = False):
+    """(max |X|^2, flat index) of a `new_key_result` record (after the producing launch has completed); a complex128
+    launch leaves the maximum as a double."""
+    m2 = rec.view(_torch().float64)[0] if complex128 else rec.view(_torch().float32)[0]
+    return float(m2.item()), int(rec[1].item())
 
 
 def argmax_key_take(key, n_per_row: int, gmax, gflat, x2=None, out_row=None):

@@ -418,7 +418,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     ring = g_ahead + 2
     distinct = list({id(x): x for x in inputs}.values())
     # the main pass leaves its true global arg-max in a key (no per-row arrays): every dataset must take that kernel
-    use_keys = x0.dtype == torch.complex64 and all(dev.ramp_native(x, plan.n_out, plan.pad_left) for x in distinct)
+    use_keys = all(dev.key_native(x, plan.n_out, plan.pad_left) for x in distinct)
+    c128 = x0.dtype == torch.complex128
     # guess stage: coarse spectra + exact check of the candidates (both precisions); else the windowed L1 norm's winner
     use_guess = (os.environ.get("XM_GUESS_L1") is None and plan.window is not None
                  and all(dev.guess_supported(x, plan.n_out, plan.pad_left) for x in distinct))
@@ -435,12 +436,13 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         band = plan.extra["guess_band"] = float(min(0.95, max(0.25, 0.9 * inside)))
     if os.environ.get("XM_GUESS_BAND"):  # tuning switch
         band = float(os.environ["XM_GUESS_BAND"])
+    l1_keys = use_keys and not c128 and not use_guess  # round 2's guess stage leaves its winner in a key (complex64)
     key = ("spec_bufs", nb, str(rd), ring, use_guess)
     bufs = plan.extra.get(key)
     if bufs is None:
         sel_rd = torch.float32 if use_guess else rd
         bufs = plan.extra[key] = dict(
-            norm=[None if (use_keys or use_guess) else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
+            norm=[None if (l1_keys or use_guess) else torch.empty(nb, dtype=rd, device=x0.device) for _ in range(ring)],
             est=[torch.empty(nb, dtype=torch.float32, device=x0.device) if use_guess else None for _ in range(ring)],
             wkey=dev.new_argmax_key(x0.device) if use_guess else None,
             zero_idx=torch.zeros(nb, dtype=torch.int32, device=x0.device),
@@ -496,11 +498,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             dev.guess_rows(inputs[j], n, plan.extra["window32"], bufs["est"][b], bufs["gkey"][b])
         else:
             dev.row_l1(inputs[j], plan.window, plan.pad_left, out=bufs["norm"][b], n_used=n_used, sub_step=sub_step,
-                       key=bufs["gkey"][b])
+                       key=bufs["gkey"][b] if l1_keys else None)
         if trace is not None:
             ev["pre1"].record()
         sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
-                           key=None if use_guess else bufs["gkey"][b], slot=bufs["sel_slots"][b],
+                           key=bufs["gkey"][b] if l1_keys else None, slot=bufs["sel_slots"][b],
                            refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
                            if use_guess else None)
 
@@ -540,7 +542,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res, ev = results[i], events[i]
         ev["verify_event"].synchronize()
         if use_keys:
-            m2, fl = dev.read_key_result(bufs["vres"][b])
+            m2, fl = dev.read_key_result(bufs["vres"][b], c128)
             tmax, trow = m2 ** 0.5, fl // n
         else:
             tmax, trow = float(bufs["vmax"][b].item()) ** 0.5, int(bufs["vflat"][b].item()) // n
