@@ -26,7 +26,8 @@ XM_ERR_HIP = -3
 XM_ERR_NO_DEVICE = -4
 
 LIB_NAME = "libxmris_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# (XMRIS_AMD_LIB: another build of the same library, for A/B runs of kernel variants on one box)
+LIB_PATH = os.environ.get("XMRIS_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

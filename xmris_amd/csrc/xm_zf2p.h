@@ -291,6 +291,11 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       // first row of a chunk: thread 0 claims the chunk after next right after the prefetch is issued; the ticket
       // is back by the last exchange and goes through LDS in front of one of the transform's own barriers
       const bool claim = off == 0u;  // workgroup-uniform
+      // NB the compiler waits for the ticket right here (s_waitcnt vmcnt(0) behind the atomic: its wave-wide rewrite
+      // of the atomic reads the value back at once), i.e. the first wave of the workgroup sits out the prefetch just
+      // issued.  Moving that wait into the hook (atomic optimiser off, "+ gridDim.x" deferred) made the kernel SLOWER:
+      // 1.011 -> 1.110 ms on one box (round 3, same-box A/B of two builds) -- the stall spaces each workgroup's loads
+      // from its stores; it stays.
       unsigned ticket = 0;
       if (claim && tt == 0u) ticket = atomicAdd(A.queue, 1u) + gridDim.x;
       FFT::run_cols(v, lds, tw, (int)tt, (int)cc, [&]() {
