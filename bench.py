@@ -40,14 +40,32 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# HBM traffic of ONE launch of the main kernel on the default workload (65,536 x 4096 -> 8192, c64), from the
-# rocprofv3 PMC passes committed in profiles/r02/pmc_main_kernel.txt (separate --pmc runs, scripts/pmc.sh) for the
-# default (speculative) schedule's main kernel k_zf2p<..., 13, 11> = write + phase ramp + global arg-max key:
-# FETCH_SIZE 1,049,200.7 KB -- gfx950 reports a wide coalesced streaming read at exactly half its bytes
-# (MI355X_MICROARCH.md, section HBM), hence x2 -- plus WRITE_SIZE 4,197,403.4 KB (exact for 16-byte streaming stores).
-# A constant typed in here, NOT a measurement of the run that prints it (`traffic_static` in the JSON line).
-PMC_TRAFFIC_BYTES_C3_C64 = int((2 * 1049200.7 + 4197403.4) * 1024)
-PMC_SOURCE = "profiles/r02/pmc_main_kernel.txt"
+# HBM traffic of ONE launch of the main kernel comes from the rocprofv3 counter passes of the SAME kernel on the SAME
+# workload, kept as a small JSON next to their text output (scripts/collect_profiles.sh -> scripts/pmc_json.py:
+# separate --pmc runs; FETCH_SIZE x 2 -- gfx950 reports a wide coalesced streaming read at half its bytes,
+# MI355X_MICROARCH.md section HBM -- plus WRITE_SIZE, exact for 16-byte streaming stores).  bench.py reads that file and
+# refuses the number (traffic: null) when the kernel it launches or the workload differs from what was profiled: a
+# figure from another kernel cannot go stale silently.
+PMC_FILES = {"c64": "profiles/r03/pmc_main_kernel.json", "c128": "profiles/r03/pmc_c128_main.json"}
+
+
+def pmc_traffic(dtype_key, kernel_name, nv, nt, N):
+    """(bytes per launch or None, provenance string) for `kernel_name` on nv x nt -> N from the committed counter file."""
+    path = os.path.join(ROOT, PMC_FILES[dtype_key])
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, f"no counter file ({PMC_FILES[dtype_key]})"
+    want = kernel_name.split(" (")[0].replace(" ", "")
+    have = str(rec.get("kernel", "")).replace(" ", "")
+    if have != want:
+        return None, f"{PMC_FILES[dtype_key]} profiles {rec.get('kernel')!r}, this run launches {kernel_name!r}"
+    if [rec.get("voxels"), rec.get("n_time"), rec.get("target_points")] != [nv, nt, N]:
+        return None, f"{PMC_FILES[dtype_key]} was collected on another workload"
+    total = int((2.0 * float(rec["FETCH_SIZE_KB"]) + float(rec["WRITE_SIZE_KB"])) * 1024)
+    return total, (f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of this kernel on this workload, "
+                   f"{PMC_FILES[dtype_key]} (commit {rec.get('commit', '?')}); not re-measured in this run")
 
 
 def synth_fids(torch, n_voxel, n_time, dt, voxel_offset, n_voxel_total, device, dtype, seed=42, star=None):
@@ -178,6 +196,15 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
+
+    # the all-cores CPU baseline's worker processes are forked NOW, before anything can have touched a GPU
+    cpu_pool = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_cpu_baseline:
+        try:
+            dt0 = 1.0 / 5000.0
+            cpu_pool = CpuPool(min(16384, args.voxels), args.n_time, np.arange(args.n_time) * dt0, args.target_points, args.lb)
+        except Exception as e:  # noqa: BLE001
+            print(f"all-cores CPU baseline unavailable: {e!r}", file=sys.stderr)
 
     # Libraries chat on stdout (RCCL prints a five-line banner at communicator creation, gloo a line per rank): the
     # contract is ONE JSON line there.  File descriptor 1 is pointed at stderr for the whole run; the result line goes
@@ -357,10 +384,12 @@ def main():
     if args.warmup:
         run_steps(args.warmup, False)
     barrier()
+    cpu0 = sum(os.times()[:2])
     t_start = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t_start
+    cpu_cores = (sum(os.times()[:2]) - cpu0) / elapsed  # this process's threads, in cores, over the timed region
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if rccl_group is not None else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=rccl_group)
@@ -378,10 +407,10 @@ def main():
         kernel = ("k_zf2p<FftPlan<4096,256,16,16,16>, " + ("13" if speculate else "9") + ", 11>" if hot
                   else "xm_pipeline_fused_ramp main pass")
     else:
-        kernel = ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("29" if speculate else "9") + ">" if hot
+        kernel = ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
                   else "xm_pipeline_fused_ramp main pass")
     kernel += " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
-    static_traffic = (PMC_TRAFFIC_BYTES_C3_C64 if (nv, nt, N, args.dtype) == (65536, 4096, 8192, "c64") else None)
+    traffic, traffic_source = pmc_traffic(args.dtype, kernel, nv, nt, N)
 
     result = {
         "metric": "spectra/sec (zero_fill->apodize->FFT->autophase), n_time=4096; HBM-roofline %",
@@ -405,9 +434,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": static_traffic, "traffic_static": True,
-            "traffic_source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of "
-                              "this kernel on this workload, " + PMC_SOURCE,
+            "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
         },
         "breakdown_ms": {
@@ -435,9 +462,19 @@ def main():
         "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0)}
                         if speculate else {"enabled": False}),
         "prime_ms": args.prime_ms,
+        "host_cores_used_rank0": cpu_cores,
     }
     if world > 1:
         result["rccl_ranks"] = rccl_ranks  # None: the barrier / timing reduction ran on gloo (see stderr)
+        # every rank reports how its host kept up (stderr): the search latency must stay below the look-ahead (two
+        # device periods) or the searches pace the steps
+        per = times["period_ms"]
+        print(f"[rank {rank}] search_latency_exchange_to_use {np.mean(times['solve_ms']):.3f} ms (max {np.max(times['solve_ms']):.3f}), "
+              f"device_period median {np.median(per) if per else float('nan'):.3f} ms, searches owned "
+              f"{len(times['gen_ms'])}/{args.steps}, generations {np.mean(times['gen_ms']) if times['gen_ms'] else float('nan'):.3f} ms, "
+              f"team budget {aps.default_threads()} threads on {len(os.sched_getaffinity(0))} CPUs, this process used "
+              f"{cpu_cores:.2f} cores, ms/step {ms_per_step:.3f}",
+              file=sys.stderr)
     if not args.no_footnotes and world == 1:
         result.update(footnotes(torch, pipeline, dev, xs, t, (out, out_b), plan, N, args, speculate, main_ms, alg_bytes))
         if speculate and "heterogeneous" in result:
@@ -447,8 +484,13 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, t, N, args.lb, args.cpu_seconds, nv)
-        result["cpu_baseline_all_cores"] = cpu_baseline_threads(x, t, N, args.lb, nv,
-                                                                result["cpu_baseline"]["de_solve_s"])
+        if cpu_pool is not None:
+            try:
+                sample = x[:cpu_pool.shape[0]].to(torch.complex64).cpu().numpy()
+                result["cpu_baseline_all_cores"] = cpu_pool.run(sample, nv, result["cpu_baseline"]["de_solve_s"])
+            except Exception as e:  # noqa: BLE001 -- the headline must not die with a worker
+                result["cpu_baseline_all_cores"] = {"error": repr(e)[:200]}
+            cpu_pool.close()
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
@@ -543,6 +585,8 @@ def hetero_note(torch, pipeline, x, t, outs, plan, args, miss_penalty_ms):
         for _ in range(n):
             sets.append(synth_hetero(torch, nv, nt, dt, seed, x.device, x.dtype)[0])
             seed += 1
+        if steps == 0:  # first use of these buffers: untimed (the headline has its warm-up too); results not counted
+            pipeline.run_stream(sets[:2], [outs[0], outs[1]], plan, speculate=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = pipeline.run_stream(sets, [outs[k % 2] for k in range(n)], plan, speculate=True)
@@ -590,7 +634,8 @@ def c128_note(torch, pipeline, xs, t, N, args, speculate):
     hot = (x2[0].shape[1], N) == (4096, 8192)
     return {"voxels": nv, "steps": k2, "value": nv / (ms2 * 1e-3), "ms_per_step": ms2, "dtype": "f64",
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_zf2d<FftPlan<4096,256,16,16,16>, ...>" if hot else "xm_pipeline_fused_ramp main pass")
+                         "kernel": ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
+                                   else "xm_pipeline_fused_ramp main pass")
                                    + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")"),
                          "achieved": bytes2 / (main2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes2,
@@ -641,34 +686,83 @@ def cpu_baseline(x, t, N, lb, budget_s, nv_full):
     }
 
 
-def cpu_baseline_threads(x, t, N, lb, nv_full, t_de, n_sample=32768, chunk=256):
-    """the same oracle calls with the voxel axis sharded over the host's cores (numpy's
-    pocketfft and ufuncs release the GIL, so a thread pool scales; no fork/exec after the GPU is initialised).
-    Wall time of the streaming stages on `n_sample` voxels, projected to the full count, plus the one DE solve."""
-    from concurrent.futures import ThreadPoolExecutor
+def _cpu_worker(shm_name, shape, t, N, lb, tasks, results):
+    """Worker process of the all-cores CPU baseline (forked before the parent initialised the GPU): the oracle's
+    streaming stages on row ranges of the shared sample, one numpy thread per process like a reference user's."""
+    from multiprocessing import shared_memory
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xmris_oracle as orc
 
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    n_sample = min(n_sample, x.shape[0])
-    xs = x[:n_sample].cpu().numpy().astype(np.complex128)
-
-    def work(lo):
-        spec, inf = orc.pipeline_values(xs[lo:lo + chunk], t, N, lb, solve=False)
+    shm = shared_memory.SharedMemory(name=shm_name)
+    xs = np.ndarray(shape, dtype=np.complex64, buffer=shm.buf)
+    while True:
+        job = tasks.get()
+        if job is None:
+            break
+        lo, hi = job
+        t0 = time.perf_counter()
+        spec, inf = orc.pipeline_values(xs[lo:hi].astype(np.complex128), t, N, lb, solve=False)
         amax = float(np.abs(inf["slice"]).max())
         orc.phase_values(spec, inf["freq"], 1, 10.0, 20.0, inf["pivot"])
-        return amax
+        results.put((hi - lo, time.perf_counter() - t0, amax))
+    shm.close()
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(0, n_sample, chunk)))
-    wall = time.perf_counter() - t0
-    per_spec = wall / n_sample
-    return {
-        "value": nv_full / (nv_full * per_spec + t_de), "unit": "spectra/s", "cores": cores, "kind": "port",
-        "sample": f"oracle sharded over {cores} threads in chunks of {chunk} voxels, first {n_sample} of {nv_full} voxels "
-                  f"in {wall:.2f} s wall; DE solve {t_de:.3f} s once per dataset (single-threaded scipy)",
-        "streaming_spectra_per_s": 1.0 / per_spec,
-    }
+
+class CpuPool:
+    """the oracle with the voxel axis sharded over the host's cores by a PROCESS pool.  The
+    workers are forked at the very start of the run -- before anything touches the GPU (a process that has initialised
+    HIP must not fork) -- and sleep on a queue until the GPU measurements are done."""
+
+    def __init__(self, n_sample, n_time, t, N, lb):
+        from multiprocessing import get_context, shared_memory
+
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            cpus = int(int(quota) / int(period)) if quota != "max" else 1 << 30
+        except (OSError, ValueError):
+            cpus = 1 << 30
+        self.workers = max(1, min(cpus, len(os.sched_getaffinity(0)), 64))
+        self.shape = (n_sample, n_time)
+        self.shm = shared_memory.SharedMemory(create=True, size=n_sample * n_time * 8)
+        ctx = get_context("fork")
+        self.tasks, self.results = ctx.Queue(), ctx.Queue()
+        self.procs = [ctx.Process(target=_cpu_worker, args=(self.shm.name, self.shape, t, N, lb, self.tasks, self.results),
+                                  daemon=True) for _ in range(self.workers)]
+        for p in self.procs:
+            p.start()
+
+    def run(self, sample, nv_full, t_de, chunk=256):
+        """`sample`: complex64 host array of self.shape (the first rows of the benchmark's dataset)."""
+        n_sample = self.shape[0]
+        np.ndarray(self.shape, dtype=np.complex64, buffer=self.shm.buf)[:] = sample
+        jobs = [(lo, min(n_sample, lo + chunk)) for lo in range(0, n_sample, chunk)]
+        t0 = time.perf_counter()
+        for j in jobs:
+            self.tasks.put(j)
+        done = 0
+        for _ in jobs:
+            done += self.results.get(timeout=600)[0]
+        wall = time.perf_counter() - t0
+        per_spec = wall / done
+        return {
+            "value": nv_full / (nv_full * per_spec + t_de), "unit": "spectra/s", "cores": self.workers, "kind": "port",
+            "pool": "processes, forked before the GPU was initialised; one numpy thread each",
+            "sample": f"oracle sharded over {self.workers} worker processes in chunks of {chunk} voxels, first {n_sample} of "
+                      f"{nv_full} voxels in {wall:.2f} s wall; DE solve {t_de:.3f} s once per dataset (single-threaded scipy)",
+            "streaming_spectra_per_s": 1.0 / per_spec,
+        }
+
+    def close(self):
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=10)
+        try:
+            self.shm.close()
+            self.shm.unlink()
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

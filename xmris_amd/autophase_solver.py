@@ -80,6 +80,35 @@ def index_width_of(coords: np.ndarray, peak_width: float) -> int:
     return max(1, int(round((peak_width / 2.0) / step)))
 
 
+def _cpu_share() -> int:
+    """CPUs this process may use: scheduler affinity, capped by the cgroup v2 quota."""
+    import os
+
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cpus
+
+
+def scarce_cpus() -> bool:
+    """Several ranks on few cores (fewer than four per rank): host waits on device events should BLOCK (interrupt)
+    instead of spinning -- a spinning wait of one rank takes the core another rank's search team is running on."""
+    import os
+
+    if os.environ.get("XM_BLOCKING_SYNC"):  # tuning switch
+        return os.environ["XM_BLOCKING_SYNC"] != "0"
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return local_world > 1 and _cpu_share() < 4 * local_world
+
+
 def default_threads() -> int:
     """Team size for the native objective: a power of two, at most 16 and at most HALF of this process's share of
     the CPUs it may use (scheduler affinity and the cgroup v2 quota, divided by the ranks torchrun started on

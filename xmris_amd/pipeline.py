@@ -138,7 +138,7 @@ class Selection:
             dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
             dev.gather_row_c128(x2, self.h_flat, n, out=x1)
         dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
-        self.event = torch.cuda.Event()
+        self.event = torch.cuda.Event(blocking=aps.scarce_cpus())
         self.event.record()
 
     def wait(self):
@@ -461,6 +461,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     sel = [None] * ring
     events = [dict() for _ in range(n_sets)]
     results = [None] * n_sets
+    blocking = aps.scarce_cpus()
     iw = aps.index_width_of(plan.freq, peak_width)
     # The guess needs a ranking, not the norm itself: samples whose window weight is negligible are not read.
     # n_used = the leading samples that carry all but 1e-3 of the window's total weight (rounded up to 256).
@@ -623,7 +624,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             ev["main1"].record()
         if not use_keys:
             dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
-        ev["verify_event"] = torch.cuda.Event()
+        ev["verify_event"] = torch.cuda.Event(blocking=blocking)
         ev["verify_event"].record()
         unverified.append(i)
         if trace is not None:

@@ -152,8 +152,10 @@ class ShmExchange:
             if cond():
                 return
         t_end = time.monotonic() + self.timeout_s
+        nap = 2e-5  # backs off to 0.15 ms: what is waited for here is a search of a millisecond or more
         while not cond():
-            time.sleep(2e-5)
+            time.sleep(nap)
+            nap = min(1.5e-4, nap * 1.5)
             if time.monotonic() > t_end:
                 raise TimeoutError("ShmExchange: a rank did not arrive (is it still running?)")
 
