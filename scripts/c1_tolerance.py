@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0] (README quick start: 5 x 1024 noise FIDs, zero_fill(2048), apodize_exp(lb=5), to_spectrum,
+autophase) end to end on the GPU against the CPU oracle: |dp0|, |dp1| and the relative error of the phased spectra for
+the injected-parameter route, the own solve with the native polish and the own solve with the numpy-driven polish
+(the default of one-dataset calls), both storage precisions.  Output kept under profiles/ (north_star: <= 1e-5)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import xmris_oracle as orc  # noqa: E402
+from xmris_amd import device as dev  # noqa: E402
+from xmris_amd import pipeline as pipe  # noqa: E402
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+rng = np.random.default_rng(42)
+t = np.linspace(0, 1, 1024)
+x = rng.standard_normal((5, 1024)) + 1j * rng.standard_normal((5, 1024))
+ref, info = orc.pipeline_values(x.astype(np.complex128), t, 2048, 5.0, peak_width=100)
+print(f"oracle: flat index {info['flat_idx']}, (p0, p1) = ({info['p0']:.9f}, {info['p1']:.9f}), nfev {info['nfev']}")
+for dtype in ("complex128", "complex64"):
+    xd = dev.to_device(x.astype(dtype))
+    out, res, _ = pipe.run(xd, t, 2048, 5.0, params=(info["p0"], info["p1"]))
+    print(f"[{dtype}] oracle's (p0, p1) injected:          spectrum rel err {relerr(out.cpu().numpy(), ref):.3e}  "
+          f"(flat index {'equal' if res.flat_index == info['flat_idx'] else 'DIFFERENT'})")
+    for polish in ("native", "numpy"):
+        out, res, _ = pipe.run(xd, t, 2048, 5.0, polish=polish)
+        print(f"[{dtype}] own solve, polish={polish:6s}: |dp0| {abs(res.p0 - info['p0']):.3e} deg  |dp1| {abs(res.p1 - info['p1']):.3e} deg  "
+              f"nfev {res.nfev}  spectrum rel err {relerr(out.cpu().numpy(), ref):.3e}  |X| rel err "
+              f"{relerr(np.abs(out.cpu().numpy()), np.abs(ref)):.3e}")

@@ -82,9 +82,13 @@ def _check(mods, oracle, x, t, target, lb, dtype, dp_tol=1e-6):
           f"f_ref={f_ref:.12g} f_mine={f_mine:.12g}")
     assert dp[0] < dp_tol and dp[1] < dp_tol
     assert f_mine <= f_ref + 1e-6 * abs(f_ref)
-    # a (p0, p1) shift of dp degrees moves the phased spectrum by ~dp*pi/180 relative: 1e-4 covers the
-    # flat-landscape noise case (dp ~ 1e-3 deg), everything else sits at the storage-precision floor
-    assert _relerr(out2.cpu().numpy(), ref) < (1e-4 if dp_tol > 1e-6 else (1e-5 if dtype == "complex64" else 1e-9))
+    # a (p0, p1) shift of dp degrees moves the phased spectrum by ~dp*pi/180 relative.  Flat landscape (README noise,
+    # dp_tol > 1e-6): the polish's end point follows the last bits of the slice -- measured (profiles/r03/
+    # c1_tolerance.txt, one-dataset calls polish on the numpy objective): complex128 3.3e-6 (north_star's 1e-5 holds
+    # at the reference's precision), complex64 1.1e-5 (its slice differs from the oracle's at 1e-7 already); everything
+    # else sits at the storage-precision floor
+    flat_tol = 1e-5 if dtype == "complex128" else 3e-5
+    assert _relerr(out2.cpu().numpy(), ref) < (flat_tol if dp_tol > 1e-6 else (1e-5 if dtype == "complex64" else 1e-9))
     np.testing.assert_allclose(np.abs(out2.cpu().numpy()), np.abs(ref), rtol=0, atol=2e-6 * np.abs(ref).max()
                                if dtype == "complex64" else 1e-12 * np.abs(ref).max())
     return dp
@@ -176,7 +180,7 @@ def test_run_stream_equals_one_dataset_at_a_time(mods, overlap):
     torch.cuda.synchronize()
     assert len(results) == len(trace) == 5
     for k, (xd, od, r) in enumerate(zip(sets, outs, results)):
-        ref_out, ref_res, _ = pipe.run(xd, t, target, 5.0)
+        ref_out, ref_res, _ = pipe.run(xd, t, target, 5.0, polish="native")  # (run_stream polishes natively)
         assert (r.flat_index, r.target_idx, r.pivot) == (ref_res.flat_index, ref_res.target_idx, ref_res.pivot), k
         assert r.flat_index // target == (7 * k + 3) % nv
         assert (r.p0, r.p1) == (ref_res.p0, ref_res.p1), k

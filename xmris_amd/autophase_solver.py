@@ -322,7 +322,17 @@ def polish_lbfgsb(obj, x0, bounds, force_scipy: bool = False):
                                          status=0 if task[0] == 4 else (1 if (state["nfev"] > maxfun or nit >= maxiter) else 2))
 
 
-def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None):
+def _numpy_objective(sl, coords, pivot, target_idx, index_width, method):
+    """The objective as the reference evaluates it (phasing.py:100-157 on plain ndarrays): numpy ufuncs, numpy's
+    summation order, the platform's libm / SVML -- what `engine="scipy"` drives."""
+    if method == "acme":
+        return lambda x: acme_score(x, sl, coords, pivot)
+    if method == "peak_minima":
+        return lambda x: peak_minima_score(x, sl, coords, pivot, target_idx, index_width)
+    return lambda x: roi_positivity_score(x, sl, coords, pivot, target_idx, index_width)
+
+
+def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None, polish="native"):
     """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
     run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective
     values, objectives vectorised over host cores), the final L-BFGS-B polish is scipy's, exactly as
@@ -339,7 +349,18 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, t
     t1 = time.perf_counter()
     # the polish's isolated evaluations below run serially (the pool is parked outside xm_solver_de)
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
-    res = polish_lbfgsb(obj, np.copy(x), bounds)
+    if polish == "numpy":
+        # The polish walks a finite-difference gradient (steps of 1e-8 degrees): on a flat landscape (pure noise, the
+        # README quick start) the LAST BITS of the objective decide where it ends, and the native objective's differ
+        # from numpy's (vectorised log / sincos recurrence, its own summation order).  Driving scipy's minimiser with
+        # the numpy objective from the generations' best member reproduces the reference's polish bit for bit
+        # whenever the generations took the same decisions -- at ~0.15 ms per evaluation instead of 6 us, which a
+        # single accessor call can afford and a stream of datasets cannot.
+        fn = _numpy_objective(sl, coords, pivot, target_idx, index_width, method)
+        fun = float(fn(x))
+        res = scipy.optimize.minimize(fn, np.copy(x), method="L-BFGS-B", bounds=bounds)
+    else:
+        res = polish_lbfgsb(obj, np.copy(x), bounds)
     nfev += res.nfev
     lo = np.array([b[0] for b in bounds])
     hi = np.array([b[1] for b in bounds])
@@ -352,10 +373,12 @@ def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, t
 
 
 def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, index_width: int,
-          method: str = "acme", p0_only: bool = False, disp: bool = False, engine: str = "native", threads=None):
+          method: str = "acme", p0_only: bool = False, disp: bool = False, engine: str = "native", threads=None,
+          polish: str = "native"):
     """phasing.py:257-287.  Returns (p0, p1, OptimizeResult).  engine="native" (default) runs the
     optimiser's generations in libxmris_hip.so; engine="scipy" calls scipy's driver with the numpy
-    objectives above (the reference's own route, ~15x slower; kept for cross-checks)."""
+    objectives above (the reference's own route, ~15x slower; kept for cross-checks).  polish="numpy" (native engine):
+    the final L-BFGS-B step is driven with the numpy objective, as the reference's is (see `_solve_native`)."""
     import scipy.optimize
 
     sl = np.asarray(sl, dtype=np.complex128)
@@ -363,7 +386,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     if method not in METHODS:
         raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
     if engine == "native" and len(sl) >= 2:
-        opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads)
+        opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads, polish)
         return float(opt.x[0]), (float(opt.x[1]) if not p0_only else 0.0), opt
     if method == "acme":
         fn, args = acme_score, (sl, coords, pivot)

@@ -152,7 +152,7 @@ class Selection:
 
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
                      p0_only=False, exchange=None, rank_offset_rows=0, disp=False, on_host_phase=None,
-                     selection: "Selection | None" = None, threads=None):
+                     selection: "Selection | None" = None, threads=None, polish="native"):
     """phasing.py:226-287 on the outputs of the pre-pass.  `exchange(max_abs, flat)` may merge the
     per-rank winners (returns (owner_is_me, global_flat)); default = single device.
     `on_host_phase()` is called once the device has nothing left to do for this dataset until the
@@ -194,7 +194,7 @@ def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", pea
             on_host_phase()
         iw = aps.index_width_of(plan.freq, peak_width)
         p0, p1, opt = aps.solve(sl, plan.freq, pivot, target_idx, iw, method=method, p0_only=p0_only, disp=disp,
-                                threads=threads)
+                                threads=threads, polish=polish)
         res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
         res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
     elif on_host_phase is not None:
@@ -203,12 +203,20 @@ def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", pea
 
 
 def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=100, target_coord=None,
-        p0_only: bool = False, out=None, plan: PipelinePlan | None = None, params=None):
+        p0_only: bool = False, out=None, plan: PipelinePlan | None = None, params=None, polish: str | None = None):
     """Fused hot path on ``x2`` = [n_batch, n_time] complex rows resident in HBM.
 
     Returns (phased [n_batch, n_out] tensor, AutophaseResult, plan).  `params=(p0, p1)` skips the
-    solver (used by parity tests that inject the oracle's parameters)."""
+    solver (used by parity tests that inject the oracle's parameters).  `polish`: "numpy" (default for this
+    one-dataset call, `XMRIS_AMD_POLISH` overrides) drives the search's final L-BFGS-B step with the numpy objective
+    like the reference does -- (p0, p1) then equal the reference's route to the last bit also on flat landscapes --
+    "native" keeps it in the library (what `run_stream` does: ~0.1 ms instead of ~5-10 ms)."""
+    import os
+
     import torch
+
+    if polish is None:
+        polish = os.environ.get("XMRIS_AMD_POLISH", "numpy")
 
     if plan is None:
         plan = make_plan(x2, t, target_points, lb)
@@ -220,7 +228,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     if params is None:  # arg-max reduction, row gather, fp64 slice and D2H all queued without host syncs
         sel = Selection(x2, plan, pre.absmax2, pre.argidx, index_from_slice=True)
         res, _ = select_and_solve(x2, plan, pre.absmax2, pre.argidx, method, peak_width, target_coord, p0_only,
-                                  selection=sel, threads=aps.burst_threads())  # one search, nothing beside it
+                                  selection=sel, threads=aps.burst_threads(), polish=polish)  # one search, nothing beside it
     else:
         res = _selection_only(pre, plan, target_coord)
     if params is not None:

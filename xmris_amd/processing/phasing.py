@@ -143,6 +143,10 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
 
     if method not in aps.METHODS:
         raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+    import os
+
+    # one accessor call, one search: the final polish runs on the numpy objective like the reference's (pipeline.run)
     p0_opt, p1_opt, _ = aps.solve(work, work_coords, pivot, target_idx, index_width, method=method,
-                                  p0_only=p0_only, disp=kwargs.get("disp"), threads=aps.burst_threads())
+                                  p0_only=p0_only, disp=kwargs.get("disp"), threads=aps.burst_threads(),
+                                  polish=os.environ.get("XMRIS_AMD_POLISH", "numpy"))
     return like_input(_phase_labeled(src, x, dim, p0_opt, p1_opt, pivot), da)  # phasing.py:290
