@@ -484,3 +484,64 @@ def test_lean_polish_is_scipys_minimize_to_the_bit(oracle):
     # the fallback is the public entry point itself
     fb = aps.polish_lbfgsb(obj, np.copy(x0), bounds, force_scipy=True)
     assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev
+
+
+def test_restated_xarray_semantics_one_by_one(monkeypatch):
+    """The reference leans on four xarray behaviours that this package has to restate for its own container (and
+    that `tests/_fake_xarray.py` cannot vouch for -- it only carries data in and out).  One assertion each, against
+    xarray's DOCUMENTED semantics (xarray 2025.6 API reference / user guide), on the host layer alone:
+
+    * `DataArray.pad` (fid.py:251): "coordinates will be padded with ... the 'constant' mode with fill_value
+      dtypes.NA" -- every coordinate along the padded dimension is NaN-filled; the reference then overwrites the
+      dimension coordinate only when it has more than one entry (fid.py:254-263);
+    * `DataArray.roll(roll_coords=True)` (fourier.py:31-32): "roll_coords: indicates whether to roll the coordinates
+      by the offset too" -- ALL coordinates along the rolled dimension move with the data, attrs kept;
+    * binary arithmetic (fid.py:139, phasing.py:73): the result's name is kept only "if all operands share it"
+      (`xarray.core.utils.result_name`): the other operand is the coordinate of `dim`, named `dim`;
+    * `DataArray.isel({d: i})` with integers (phasing.py:241-242): the dimension is dropped, the result is the
+      1-D slice through that position -- autophase searches on exactly that slice."""
+    import _numpy_device
+
+    from xmris_amd import processing
+    from xmris_amd.labeled import Coordinate, LabeledArray
+
+    _numpy_device.install(monkeypatch)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 6)) + 1j * rng.standard_normal((2, 6))
+    t = np.arange(6) * 0.5
+    aux = np.arange(6) * 10.0  # a second, non-dimension coordinate along `time`
+    da = LabeledArray(x, ("voxel", "time"), {"time": Coordinate("time", t, {"units": "s"}),
+                                             "echo": Coordinate("time", aux, {"note": "aux"})}, {"k": 1}, "fid")
+    # pad: the dimension coordinate is extrapolated (more than one entry), the other coordinate along it is NaN-filled
+    zf = processing.fid.zero_fill(da, target_points=10, position="symmetric")
+    np.testing.assert_array_equal(zf.coords["time"].values, (t[0] - 2 * 0.5) + np.arange(10) * 0.5)
+    np.testing.assert_array_equal(zf.coords["echo"].values, np.r_[np.nan, np.nan, aux, np.nan, np.nan])
+    assert zf.coords["echo"].attrs == {"note": "aux"} and zf.name == "fid"  # pad keeps the name
+    one = LabeledArray(x[:, :1], ("voxel", "time"), {"time": Coordinate("time", t[:1])}, {}, None)
+    zf1 = processing.fid.zero_fill(one, target_points=3)  # one entry: nothing to extrapolate from, the NaN fill stays
+    np.testing.assert_array_equal(zf1.coords["time"].values, np.r_[t[0], np.nan, np.nan])
+    # roll(roll_coords=True): both coordinates along the dimension are rolled by n // 2, attrs untouched
+    sh = processing.fourier.fftshift(da, "time")
+    np.testing.assert_array_equal(sh.values, np.roll(x, 3, axis=1))
+    np.testing.assert_array_equal(sh.coords["time"].values, np.roll(t, 3))
+    np.testing.assert_array_equal(sh.coords["echo"].values, np.roll(aux, 3))
+    assert sh.coords["time"].attrs == {"units": "s"} and sh.attrs == {"k": 1} and sh.name == "fid"
+    ish = processing.fourier.ifftshift(LabeledArray(x[:, :5], ("voxel", "time"), {"time": Coordinate("time", t[:5])}), "time")
+    np.testing.assert_array_equal(ish.coords["time"].values, np.roll(t[:5], 3))  # (n + 1) // 2 for odd n
+    # binary-op name rule: "fid" * (coordinate named "time") -> None;  "time" * "time" -> "time"
+    assert processing.fid.apodize_exp(da, lb=1.0).name is None
+    named = LabeledArray(x, ("voxel", "time"), {"time": Coordinate("time", t)}, {}, "time")
+    assert processing.fid.apodize_exp(named, lb=1.0).name == "time"
+    spec = LabeledArray(x, ("voxel", "frequency"), {"frequency": Coordinate("frequency", t - 1.0)}, {}, "frequency")
+    assert processing.phasing.phase(spec, p0=10.0).name == "frequency"
+    assert processing.phasing.phase(LabeledArray(x, ("voxel", "frequency"), {"frequency": Coordinate("frequency", t - 1.0)},
+                                                 {}, "spectrum"), p0=10.0).name is None
+    # isel: autophase works on the 1-D slice through the global arg-max of every OTHER dimension
+    y = 0.01 * x
+    y[1, 4] = 5.0 + 0.0j
+    got = processing.phasing.autophase(LabeledArray(y, ("voxel", "frequency"), {"frequency": Coordinate("frequency", t - 1.0)}),
+                                       p0_only=True)
+    assert got.attrs["phase_pivot"] == (t - 1.0)[4]  # the pivot is the coordinate at the arg-max ALONG dim ...
+    ref_p0 = __import__("xmris_amd.autophase_solver", fromlist=["solve"]).solve(
+        y[1].astype(np.complex128), t - 1.0, (t - 1.0)[4], 4, 1, p0_only=True, polish="numpy")[0]
+    assert got.attrs["phase_p0"] == ref_p0  # ... and the search ran on row 1 (the slice isel would return), not row 0
