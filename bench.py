@@ -250,19 +250,32 @@ def main():
         dist.init_process_group("gloo")
         host_group = dist.group.WORLD
         if args.dist_backend == "nccl":
-            ok = 1
+            def all_ok(ok):  # every rank learns through gloo whether EVERY rank got this far
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(flag.item())
+
+            # step by step, agreeing through gloo BEFORE the first RCCL collective: a rank whose group creation failed
+            # would otherwise leave the others waiting inside RCCL until its watchdog fires
             try:
                 rccl_group = dist.new_group(backend="nccl", device_id=device)
-                ones = torch.ones(1, dtype=torch.int32, device=device)
-                dist.all_reduce(ones, group=rccl_group)  # how many ranks RCCL really spans
-                rccl_ranks = int(ones.item())
+                made = True
             except Exception as e:  # noqa: BLE001 -- anything RCCL throws at start-up
                 print(f"[rank {rank}] RCCL group unavailable ({e!r}); barrier and timing go through gloo", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                rccl_group, rccl_ranks = None, None
+                made = False
+            if not all_ok(made):
+                rccl_group = None
+            else:
+                try:
+                    ones = torch.ones(1, dtype=torch.int32, device=device)
+                    dist.all_reduce(ones, group=rccl_group)  # how many ranks RCCL really spans
+                    rccl_ranks = int(ones.item())
+                    worked = True
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] RCCL all-reduce failed ({e!r}); barrier and timing go through gloo", file=sys.stderr)
+                    worked = False
+                if not all_ok(worked):
+                    rccl_group, rccl_ranks = None, None
         # on one node the same exchange goes through a shared-memory page (microseconds instead of two
         # loopback collectives per dataset); every rank must agree on the choice, so failures are gathered
         if args.exchange == "shm":

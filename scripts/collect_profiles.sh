@@ -4,7 +4,8 @@
 #   1. bench.py unprofiled (default K/W and the driver's --steps 20 --warmup 5) -> bench_default.json, bench_steps20.json
 #   2. bench.py under rocprofv3 --kernel-trace --stats -> bench_under_rocprof.json, bench_kernel_stats.csv,
 #      bench_kernel_trace_xm_kernels.csv
-#   3. separate --pmc passes (counters never share a run with the trace domains) for the main kernel of the
+#   3. separate --pmc passes (one rocprofv3 run per counter group, each with --kernel-trace only -- never with the
+#      sys / runtime / hip / hsa / memory-copy trace domains) for the main kernel of the
 #      speculative schedule (k_zf2p mode 13), the guess kernel and the classic schedule's pre-pass
 #      -> pmc_main_kernel.txt, pmc_guess_kernel.txt, pmc_prepass_kernel.txt
 #   3b. complex128: c128_modes.txt, pmc_c128_main.txt (k_zf2d, then k_zf2<double>), bench_c128.json, timeline_c128.txt

@@ -216,6 +216,51 @@ def test_lazy_chain_is_fused_by_autophase(xm, oracle, monkeypatch, dtype):
     assert calls == before  # fused, both times
 
 
+def test_lazy_chain_with_an_edited_intermediate_runs_staged(xm, oracle, monkeypatch):
+    """A caller may edit an intermediate of the recorded chain without looking at its data: a rescaled time
+    coordinate on the zero-filled FID (the window `apodize_exp` builds from it changes) or an extra attr.  The fused
+    path regenerates everything from the chain's root and would silently drop such edits, so `autophase` must fall
+    back to the staged calls -- same result as the eager chain with the same edits."""
+    from xmris_amd import device as dev
+    from xmris_amd.labeled import Coordinate
+
+    nv, nt = 12, 1024
+    rng = np.random.default_rng(5)
+    t = np.arange(nt) * 2e-4
+    x = (np.exp(-25 * t) * np.exp(2j * np.pi * 410 * t))[None, :] * (0.5 + rng.random(nv))[:, None] + \
+        0.02 * (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt)))
+    a, _ = _pair(xm, oracle, x.astype(np.complex128), ("voxel", "time"), {"voxel": np.arange(nv), "time": t}, {"MHz": 120.0})
+    calls = {"apodize": 0}
+    real = dev.apodize
+    monkeypatch.setattr(dev, "apodize", lambda *a_, **k_: (calls.__setitem__("apodize", calls["apodize"] + 1), real(*a_, **k_))[1])
+
+    def chain(edit):
+        zf = a.xmr.zero_fill(target_points=2048)
+        edit(zf)
+        return zf.xmr.apodize_exp(lb=5.0).xmr.to_spectrum().xmr.autophase()
+
+    def new_axis(zf):
+        zf.coords["time"] = Coordinate("time", zf.coords["time"].values * 0.5, zf.coords["time"].attrs)
+
+    def new_attr(zf):
+        zf.attrs["operator"] = "someone"
+
+    plain = chain(lambda zf: None)
+    assert calls["apodize"] == 0                      # untouched: fused
+    got = chain(new_axis)                             # (the recorded spectrum still materialises in one fused launch --
+    assert calls["apodize"] == 0                      # with the weights and coordinates as recorded)
+    monkeypatch.setenv("XMRIS_AMD_EAGER", "1")
+    eager = chain(new_axis)
+    monkeypatch.delenv("XMRIS_AMD_EAGER")
+    assert calls["apodize"] == 1
+    np.testing.assert_allclose(got.values, eager.values, rtol=0, atol=1e-9 * np.abs(eager.values).max())
+    np.testing.assert_array_equal(got.coords["frequency"].values, eager.coords["frequency"].values)
+    assert not np.array_equal(got.coords["frequency"].values, plain.coords["frequency"].values)  # the edit is honoured
+    assert abs(got.attrs["phase_p0"] - eager.attrs["phase_p0"]) < 1e-6 and got.attrs["phase_pivot"] == eager.attrs["phase_pivot"]
+    tagged = chain(new_attr)
+    assert tagged.attrs["operator"] == "someone"
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_lazy_chain_end_materialises_in_one_fused_launch(xm, oracle, monkeypatch, dtype):
     """Asking the END of a recorded `to_spectrum(apodize_exp([zero_fill](fid)))` / `to_spectrum(zero_fill(fid))` chain

@@ -84,17 +84,59 @@ def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_on
         return None
     from ..fused import spectral_pipeline
 
+    # The fused path regenerates coordinates and attrs from the ROOT.  A caller may have edited an intermediate of the
+    # recorded chain without looking at its data (`zf.coords["time"] = ...`, `zf.attrs[...] = ...`): the staged chain
+    # honours such edits, so the fused path only runs when every intermediate still carries what the recording call
+    # produced (the coordinate of the FID axis and the attrs are compared with a regenerated chain of metadata).
+    if not _chain_metadata_untouched(src, root, steps):
+        return None
     x, _ = device_data(root)
     base = root.copy(data=promote_for_float64_operand(x))  # the staged chain is complex128 from apodize_exp on
     n = root.sizes[d0]
-    extra = {}
-    if lg:  # the Lorentz-to-Gauss weights as recorded, and the lineage attrs that call stamps (fid.py:190-196)
+    # the weights as recorded (both windows), and for Lorentz-to-Gauss the lineage attrs that call stamps (fid.py:190-196)
+    extra = dict(_window=ap["_weight"])
+    if lg:
         from ..config import ATTRS
 
-        extra = dict(_window=ap["_weight"], _apodization_attrs={ATTRS.apodization_lb: ap["lb"], ATTRS.apodization_gb: ap["gb"]})
+        extra["_apodization_attrs"] = {ATTRS.apodization_lb: ap["lb"], ATTRS.apodization_gb: ap["gb"]}
     return spectral_pipeline(base, target_points=zf["target_points"] if zf is not None else n, lb=ap["lb"], dim=d0,
                              out_dim=dim, position=zf["position"] if zf is not None else "end", method=method,
                              peak_width=peak_width, target_coord=target_coord, p0_only=p0_only, **extra)
+
+
+def _chain_metadata_untouched(src: LabeledArray, root: LabeledArray, steps) -> bool:
+    """Replay the recorded steps' METADATA (host arithmetic only, nothing is computed on the device) from the root and
+    compare coordinates, attrs and names with what the chain's arrays carry now."""
+    from . import fid as _fid
+
+    nodes = []
+    node = src
+    while node.is_deferred:
+        nodes.append(node)
+        node = node._lazy.parent
+    if node is not root or len(nodes) != len(steps):
+        return False
+    replay = root
+    for (name, kw), have in zip(reversed(steps), reversed(nodes)):
+        if name == "zero_fill":
+            replay = _fid.zero_fill(replay, dim=kw["dim"], target_points=kw["target_points"], position=kw["position"])
+        elif name == "apodize_exp":
+            replay = _fid.apodize_exp(replay, dim=kw["dim"], lb=kw["lb"])
+        elif name == "apodize_lg":
+            replay = _fid.apodize_lg(replay, dim=kw["dim"], lb=kw["lb"], gb=kw["gb"])
+        elif name == "to_spectrum":
+            replay = _fid.to_spectrum(replay, dim=kw["dim"], out_dim=kw["out_dim"])
+        else:
+            return False
+        if have.dims != replay.dims or have.attrs != replay.attrs or have.name != replay.name:
+            return False
+        if set(have.coords) != set(replay.coords):
+            return False
+        for k, c in replay.coords.items():
+            hc = have.coords[k]
+            if hc.dim != c.dim or hc.attrs != c.attrs or not np.array_equal(hc.values, c.values, equal_nan=True):
+                return False
+    return True
 
 
 def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "single",
