@@ -321,3 +321,42 @@ def test_lazy_chain_end_materialises_in_one_fused_launch(xm, oracle, monkeypatch
     sp = b.xmr.zero_fill(target_points=1024).xmr.apodize_exp(lb=3.0).xmr.to_spectrum()
     _same(sp, oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(ob, target_points=1024), lb=3.0)), 1e-9)
     assert calls["pipeline_fused"] == before["pipeline_fused"] and calls["fft"] - before["fft"] == 1
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_host_resident_fids_take_the_chunked_path(xm, oracle, monkeypatch, dtype):
+    """FIDs in HOST memory (what an `xarray.DataArray` caller holds): `spectral_pipeline` and the recorded four-call
+    chain upload them chunk by chunk with the pre-pass running behind the upload, and bring the phased spectra back
+    chunk by chunk behind the main pass (`hostpath.run_host`).  Same dims / coords / attrs / (p0, p1) / spectra as the
+    device-resident route and the oracle; the lazy chain on complex64 input comes back complex128 (numpy's promotion)."""
+    from xmris_amd import hostpath
+
+    nv, nt, N = 300, 1024, 2048
+    rng = np.random.default_rng(8)
+    t = np.arange(nt) * 2e-4
+    amp = 0.5 + rng.random(nv)
+    amp[41] = 3.0
+    x = (amp[:, None] * (np.exp(-25 * t) * np.exp(2j * np.pi * 410 * t))[None, :]
+         + 0.02 * (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt)))).astype(dtype)
+    monkeypatch.setenv("XMRIS_AMD_HOST_STREAM_MIN", "1")  # (300 rows: force the chunked path)
+    calls = []
+    real = hostpath.run_host
+    monkeypatch.setattr(hostpath, "run_host", lambda *a, **k: (calls.append(1), real(*a, chunk_bytes=64 * nt * x.itemsize, **k))[1])
+    host = xm.LabeledArray(x, ("voxel", "time"), {"voxel": np.arange(nv), "time": t}, {"MHz": 120.0})
+    got = host.xmr.spectral_pipeline(target_points=N, lb=5.0)
+    assert calls == [1] and isinstance(got.data, np.ndarray) and got.dtype == np.dtype(dtype)
+    on_dev = xm.LabeledArray(xm.device.to_device(x), ("voxel", "time"), {"voxel": np.arange(nv), "time": t}, {"MHz": 120.0})
+    ref = on_dev.xmr.spectral_pipeline(target_points=N, lb=5.0)
+    assert got.dims == ref.dims and got.attrs == ref.attrs and got.name == ref.name
+    for k in ref.coords:
+        np.testing.assert_array_equal(got.coords[k].values, ref.coords[k].values)
+    np.testing.assert_array_equal(got.values, ref.values)  # the same kernels on the same rows: bit for bit
+    # the recorded chain on the host array: fused by autophase, still through the chunked path, promoted like numpy does
+    chain = host.xmr.zero_fill(target_points=N).xmr.apodize_exp(lb=5.0).xmr.to_spectrum().xmr.autophase()
+    assert calls == [1, 1] and chain.dtype == np.complex128
+    o = oracle.Labeled(x, ("voxel", "time"), {"voxel": oracle.Coord("voxel", np.arange(nv)), "time": oracle.Coord("time", t)},
+                       {"MHz": 120.0}, None)
+    oc = oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=N), lb=5.0)), peak_width=100)
+    assert chain.dims == oc.dims and set(chain.attrs) == set(oc.attrs)
+    assert abs(chain.attrs["phase_p0"] - oc.attrs["phase_p0"]) < 1e-6 and abs(chain.attrs["phase_p1"] - oc.attrs["phase_p1"]) < 1e-6
+    np.testing.assert_allclose(chain.values, oc.values, rtol=0, atol=1e-9 * np.abs(oc.values).max())

@@ -20,9 +20,14 @@ from .dims import _check_dims, term_attrs
 def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,
                       out_dim: str = DIMS.frequency, position: str = "end", method: str = "acme",
                       peak_width=100, target_coord=None, p0_only: bool = False, mode: str = "single", _window=None,
-                      _apodization_attrs=None, **kwargs):
+                      _apodization_attrs=None, _promote: bool = False, **kwargs):
     """`_window` / `_apodization_attrs` (private: the lazy chain's `apodize_lg`): the weights over the zero-filled axis
-    and the lineage attrs that replace `apodization_lb = lb`."""
+    and the lineage attrs that replace `apodization_lb = lb`.  `_promote` (private: the lazy chain on host data): widen
+    complex64 to complex128 like the staged chain does.
+
+    Data that live in HOST memory (a numpy-backed array of at least `hostpath.min_bytes()`, FID axis last) take
+    `hostpath.run_host`: upload, both passes and the download overlap chunk by chunk and the result comes back as a
+    host array."""
     src = as_labeled(da)
     _check_dims(src, dim, "zero_fill")
     if position not in ("end", "symmetric"):
@@ -36,7 +41,21 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     if method not in ("acme", "peak_minima", "positivity"):
         raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
     t = src.coords[dim].values  # apodize_exp needs the coordinate (KeyError otherwise)
+    host = _host_rows(src, dim)
+    if host is not None:
+        from . import hostpath
+
+        x2h, lead = host
+        y2, res, plan = hostpath.run_host(x2h, t, target_points, lb, position, window_host=_window, method=method,
+                                          peak_width=peak_width, target_coord=target_coord, p0_only=p0_only,
+                                          promote=_promote)
+        return like_input(_label_result(src, y2.reshape(lead + (plan.n_out,)), res, plan, dim, out_dim, target_points,
+                                        position, lb, _apodization_attrs), da)
     x, _ = device_data(src)
+    if _promote:
+        from .processing._common import promote_for_float64_operand
+
+        x = promote_for_float64_operand(x)
     ax = src.get_axis_num(dim)
     nd = x.dim()
     xm = x.movedim(ax, -1) if ax != nd - 1 else x
@@ -56,8 +75,33 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
         return like_input(out, da)
     y2, res, plan = pl.run(x2, t, target_points, lb, method=method, peak_width=peak_width,
                            target_coord=target_coord, p0_only=p0_only, plan=plan)
-    y = y2.reshape(lead + (plan.n_out,))
+    return like_input(_label_result(src, y2.reshape(lead + (plan.n_out,)), res, plan, dim, out_dim, target_points, position,
+                                    lb, _apodization_attrs), da)
 
+
+def _host_rows(src, dim):
+    """([n_batch, n] host rows, leading shape) when `src` is numpy-backed complex data large enough for the chunked
+    host path with the FID axis last; else None."""
+    from . import hostpath
+
+    if src.is_device_resident or src.get_axis_num(dim) != src.ndim - 1:
+        return None
+    x = src.data
+    if not isinstance(x, np.ndarray) or x.dtype not in (np.complex64, np.complex128) or x.nbytes < hostpath.min_bytes():
+        return None
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+    except ImportError:
+        return None
+    x = np.ascontiguousarray(x)
+    return x.reshape(-1, x.shape[-1]), tuple(x.shape[:-1])
+
+
+def _label_result(src, y, res, plan, dim, out_dim, target_points, position, lb, _apodization_attrs):
+    """Dims, coordinates, lineage attrs and name of the fused result (fid.py:254-283, fourier.py:92-111, phasing.py:76-94)."""
     n, n_out = src.sizes[dim], plan.n_out
     new_dims = tuple(out_dim if d == dim else d for d in src.dims)
     coords = {}
@@ -83,4 +127,4 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     attrs[ATTRS.phase_pivot] = res.pivot
     attrs[ATTRS.phase_pivot_coord] = out_dim
     name = src.name if src.name == dim == out_dim else None
-    return like_input(LabeledArray(y, new_dims, coords, attrs, name), da)
+    return LabeledArray(y, new_dims, coords, attrs, name)

@@ -90,8 +90,9 @@ def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_on
     # produced (the coordinate of the FID axis and the attrs are compared with a regenerated chain of metadata).
     if not _chain_metadata_untouched(src, root, steps):
         return None
-    x, _ = device_data(root)
-    base = root.copy(data=promote_for_float64_operand(x))  # the staged chain is complex128 from apodize_exp on
+    # the staged chain is complex128 from apodize_exp on (`_promote`); host-resident roots stay on the host here: the
+    # fused front end uploads them chunk by chunk, overlapped with the passes
+    base = root
     n = root.sizes[d0]
     # the weights as recorded (both windows), and for Lorentz-to-Gauss the lineage attrs that call stamps (fid.py:190-196)
     extra = dict(_window=ap["_weight"])
@@ -101,7 +102,7 @@ def _fused_chain(src: LabeledArray, dim, method, peak_width, target_coord, p0_on
         extra["_apodization_attrs"] = {ATTRS.apodization_lb: ap["lb"], ATTRS.apodization_gb: ap["gb"]}
     return spectral_pipeline(base, target_points=zf["target_points"] if zf is not None else n, lb=ap["lb"], dim=d0,
                              out_dim=dim, position=zf["position"] if zf is not None else "end", method=method,
-                             peak_width=peak_width, target_coord=target_coord, p0_only=p0_only, **extra)
+                             peak_width=peak_width, target_coord=target_coord, p0_only=p0_only, _promote=True, **extra)
 
 
 def _chain_metadata_untouched(src: LabeledArray, root: LabeledArray, steps) -> bool:
