@@ -250,6 +250,10 @@ struct Pool {
   std::vector<std::thread> th;
   alignas(128) std::atomic<uint64_t> gen{0};
   alignas(128) std::atomic<int> state{0};  // 0 parked, 1 spinning, 2 exit
+  std::atomic<int> spin_team{0};           // members (caller included) of the search that activated the pool: only
+                                           // workers with id < spin_team wake up and spin -- a pool that once served a
+                                           // 16-thread search must not spin 15 workers beside a 2-thread one (round 2
+                                           // did: ~25 cores busy under a 16-CPU quota with four searches in flight)
   std::mutex mu;
   std::condition_variable cv;
   Slot slot[kMaxWorkers + 1];
@@ -274,7 +278,7 @@ struct Pool {
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return state.load() != 0; });
+        cv.wait(lk, [&] { return state.load() == 2 || (state.load() == 1 && id < spin_team.load()); });
         if (state.load() == 2) return;
       }
       while (state.load(std::memory_order_acquire) == 1) {
@@ -300,16 +304,19 @@ struct Pool {
   }
   // (No CPU pinning: on the shared MI355X hosts the scheduler finds idle cores better than a static
   // same-L3 placement did -- measured 2.6 us vs 4.7 us per evaluation with 16 threads.)
-  void activate() {
+  void activate(int team_size) {
     {
       std::lock_guard<std::mutex> lk(mu);
+      spin_team.store(team_size);
       state.store(1);
     }
     cv.notify_all();
   }
   void park() { state.store(0, std::memory_order_release); }
   bool active() const { return state.load(std::memory_order_acquire) == 1; }
-  bool fits(int tasks, int t) const { return t - 1 <= (int)th.size() && (tasks + t - 1) / t <= kMaxLocal; }
+  bool fits(int tasks, int t) const {
+    return t - 1 <= (int)th.size() && t <= spin_team.load() && (tasks + t - 1) / t <= kMaxLocal;
+  }
   // partial sums of task j after eval(): slot[j % team].sums[5 * (j / team)]
   const double* task_sums(int j) const { return slot[j % team].sums + 5 * (j / team); }
   void eval(const Solver* sv, const double* p01r, int count, int chunks, int t) {
@@ -490,7 +497,7 @@ void xm_solver_pool_begin(int threads) {
   t_pool = p;
   if (!p) return;
   p->ensure(threads - 1);
-  p->activate();
+  p->activate(threads);
 }
 
 void xm_solver_pool_end(void) {
