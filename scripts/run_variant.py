@@ -7,7 +7,7 @@ VARIANT:
   guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass (round 2)
   coarse = the guess stage of round 3: xm_guess_rows (coarse spectra, k_zf2p<512-plan, 4, 17>) + xm_guess_refine
   rows  = write + phase ramp + per-row maxima (value only): the complex128 main pass of the speculative schedule
-DTYPE=c128 runs the complex128 kernels (use NV=32768)."""
+DTYPE=c128 runs the complex128 kernels (`all`: k_zf2d with the arg-max key and the prefetch, mode 221)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmris_amd import device as dev
@@ -32,6 +32,7 @@ hflat = torch.zeros(1, dtype=torch.int64, pin_memory=True)
 hmax = torch.zeros(1, dtype=torch.float32, pin_memory=True)
 row = torch.empty((1, nt), dtype=torch.complex128, device="cuda")
 w32 = w.to(torch.float32)
+res128 = dev.new_key_result()
 for _ in range(int(os.environ.get("REPS", 3))):
     if var == "coarse":
         dev.guess_rows(x, N, w32, est, key)
@@ -39,6 +40,8 @@ for _ in range(int(os.environ.get("REPS", 3))):
     elif var == "guess":
         dev.row_l1(x, w, 0, n_used=2304, sub_step=8, key=key)
         dev.argmax_key_take(key, N, gmax, gflat)
+    elif var == "all" and rd == torch.float64:  # complex128: the launch decodes its key itself (result record)
+        dev.pipeline_fused(x, N, 0, window=w, out=out, key_result=res128, **kw)
     else:
         dev.pipeline_fused(x, N, 0, window=w, out=out, absmax2=None if var == "all" else am, argidx=None if var == "all" else ai, **kw)
         if var == "all":
