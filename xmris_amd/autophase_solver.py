@@ -384,7 +384,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     sl = np.asarray(sl, dtype=np.complex128)
     coords = np.asarray(coords, dtype=np.float64)
     if method not in METHODS:
-        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
     if engine == "native" and len(sl) >= 2:
         opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads, polish)
         return float(opt.x[0]), (float(opt.x[1]) if not p0_only else 0.0), opt
@@ -395,7 +395,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     elif method == "positivity":
         fn, args = roi_positivity_score, (sl, coords, pivot, target_idx, index_width)
     else:
-        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
     opt = scipy.optimize.differential_evolution(
         fn, bounds=bounds, args=args, strategy="best1bin", tol=0.01, seed=42, disp=disp

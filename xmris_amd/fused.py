@@ -31,15 +31,15 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     src = as_labeled(da)
     _check_dims(src, dim, "zero_fill")
     if position not in ("end", "symmetric"):
-        raise ValueError("`position` must be either 'end' or 'symmetric'.")
+        raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
     if mode == "all":
         raise NotImplementedError(
-            "Applying autophase to each spectrum individually ('all') is not yet implemented."
+            "autophase(mode='all'), one phase pair per spectrum, is not available (nor is it in the reference)"
         )
     elif mode != "single":
-        raise ValueError("Mode must be 'single' or 'all'.")
+        raise ValueError("unknown autophase mode: 'single' expected ('all' is reserved)")
     if method not in ("acme", "peak_minima", "positivity"):
-        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
     t = src.coords[dim].values  # apodize_exp needs the coordinate (KeyError otherwise)
     host = _host_rows(src, dim)
     if host is not None:

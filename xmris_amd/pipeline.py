@@ -61,7 +61,7 @@ def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end", 
         elif position == "symmetric":
             pad_left = (n_out - n_in) // 2
         else:
-            raise ValueError("`position` must be either 'end' or 'symmetric'.")
+            raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
         tt = zero_fill_coords(t, n_out, pad_left) if len(t) > 1 else t
     win = np.exp(-np.pi * lb * tt) if lb is not None else np.ones(n_out)
     if window_host is not None:

@@ -96,7 +96,7 @@ def zero_fill(da, dim: str = DIMS.time, target_points: int = 1024, position: str
     elif position == "symmetric":
         pad_left = pad // 2
     else:
-        raise ValueError("`position` must be either 'end' or 'symmetric'.")
+        raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
     def compute():
         x, was_real = device_data(src)
         return maybe_real(dev.zero_fill(x, src.get_axis_num(dim), int(target_points), pad_left), was_real)

@@ -37,10 +37,9 @@ def _phase_labeled(src: LabeledArray, x, dim, p0, p1, pivot) -> LabeledArray:
     if pivot is not None and ATTRS.phase_pivot_coord in out.attrs:  # phasing.py:79-88
         old = out.attrs[ATTRS.phase_pivot_coord]
         if old != dim:
-            warnings.warn(
-                f"Applying phase in '{dim}', but previous phase operations "
-                f"were recorded in '{old}'. Ensure your pivot value "
-                f"({pivot}) matches the current dimension's units."
+            warnings.warn(  # (the reference warns here too; own wording)
+                f"phase along '{dim}' on data whose earlier phase steps were taken along '{old}': "
+                f"the pivot ({pivot}) is read in the units of '{dim}'"
             )
     out.attrs[ATTRS.phase_p0] = p0  # phasing.py:91-94
     out.attrs[ATTRS.phase_p1] = p1
@@ -149,12 +148,12 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
     kwargs.setdefault("disp", False)
     if mode == "all":
         raise NotImplementedError(
-            "Applying autophase to each spectrum individually ('all') is not yet implemented."
+            "autophase(mode='all'), one phase pair per spectrum, is not available (nor is it in the reference)"
         )
     elif mode != "single":
-        raise ValueError("Mode must be 'single' or 'all'.")
+        raise ValueError("unknown autophase mode: 'single' expected ('all' is reserved)")
     if method not in aps.METHODS:
-        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
     fused = _fused_chain(src, dim, method, peak_width, target_coord, p0_only, lb)
     if fused is not None:
         return like_input(fused, da)
@@ -185,7 +184,7 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
         work, work_coords = tmp.values, tmp.coords[dim].values
 
     if method not in aps.METHODS:
-        raise ValueError("Method must be 'acme', 'peak_minima', or 'positivity'")
+        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
     import os
 
     # one accessor call, one search: the final polish runs on the numpy objective like the reference's (pipeline.run)
