@@ -572,6 +572,42 @@ def test_arg_max_key_path_matches_the_per_row_path(dev):
     np.testing.assert_array_equal(row.cpu().numpy()[0], x[best].astype(np.complex128))
 
 
+@pytest.mark.parametrize("n_in,n_out,nb", [(4096, 8192, 1500), (8192, 16384, 300), (3000, 8192, 37)])
+def test_complex128_arg_max_key(dev, n_in, n_out, nb):
+    """XM_AMAX_GLOBAL_KEY for complex128 (k_zf2d: every wave leaves its (max |X|^2 bits, row) in a slot, the last
+    workgroup out merges them into the result record; the next row arrives by global_load_lds): the record against the
+    per-row maxima + xm_argmax_reduce -- the fp64 maximum to the bit, the lower row on an exact tie, a NaN row first --
+    the spectra against the launch without the key, every mode that takes it (write + ramp, write, maxima only), and
+    the predicate that says where it applies."""
+    import torch
+
+    x = _rand((nb, n_in), "complex128", seed=n_in + nb)
+    x[nb // 2] *= 3.0
+    x[nb - 3] = x[nb // 2]  # an exact tie: the lower row must win
+    xd = dev.to_device(x)
+    w = torch.linspace(1.0, 0.2, n_out, device="cuda", dtype=torch.float64)
+    assert dev.key_native(xd, n_out) and not dev.key_native(dev.to_device(x[:, :1024]), 2048)  # (k_zf2<double>: no key)
+    key, rec = dev.new_argmax_key("cuda"), dev.new_key_result()
+    for kw in (dict(phase_ramp=(0.3, 0.001)), dict(), dict(want_out=False)):
+        # (the per-row path of the SAME mode: a folded ramp factor rounds the last bits of |X|^2 differently)
+        ref = dev.pipeline_fused(xd, n_out, window=w, want_argmax=True, argmax_value_only=True, **kw)
+        m2_ref = float(ref.absmax2.max().item())
+        for _ in range(2):  # (twice: the slots need no clearing)
+            res = dev.pipeline_fused(xd, n_out, window=w, global_key=key, key_result=rec, **kw)
+            torch.cuda.synchronize()
+            m2, fl = dev.read_key_result(rec, complex128=True)
+            assert fl == (nb // 2) * n_out and m2 == m2_ref, (kw, fl, m2, m2_ref)
+        if kw.get("phase_ramp"):
+            assert torch.equal(res.out, ref.out)
+    x[5, 17] = np.nan
+    dev.pipeline_fused(dev.to_device(x), n_out, window=w, phase_ramp=(0.3, 0.001), global_key=key, key_result=rec)
+    torch.cuda.synchronize()
+    m2, fl = dev.read_key_result(rec, complex128=True)
+    assert fl == 5 * n_out and np.isnan(m2)
+    with pytest.raises(Exception, match="result record"):  # complex128 keys are decoded by the launch itself
+        dev.pipeline_fused(xd, n_out, window=w, phase_ramp=(0.3, 0.001), global_key=key)
+
+
 def test_phase_ramp_equals_phase_table(dev):
     """xm_pipeline_fused_ramp against xm_pipeline_fused with the table of the same ramp: the native (factorised) path of
     the hot kernel on every half-length plan, and the expand-to-scratch-table path elsewhere (no zero fill, odd
