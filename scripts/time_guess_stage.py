@@ -39,6 +39,25 @@ norm = torch.empty(nv, dtype=torch.float32, device="cuda")
 idx = torch.zeros(nv, dtype=torch.int32, device="cuda")
 print(f"row_l1 (n_used 2304, sub_step 8, key):   {timeit(lambda: dev.row_l1(x, win, 0, n_used=2304, sub_step=8, key=key)):8.1f} us")
 print(f"row_l1 (n_used 2304, sub_step 8, norms): {timeit(lambda: dev.row_l1(x, win, 0, out=norm, n_used=2304, sub_step=8)):8.1f} us")
+est = torch.empty(nv, dtype=torch.float32, device="cuda")
+wkey = dev.new_argmax_key(x.device)
+hmax = torch.zeros(1, dtype=torch.float32, pin_memory=True)
+hflat = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+row = torch.empty((1, nt), dtype=torch.complex128, device="cuda")
+print(f"xm_guess_rows (coarse spectra, est + key):  {timeit(lambda: dev.guess_rows(x, N, win, est, key)):8.1f} us")
+x128 = x[:32768].to(torch.complex128)
+est2 = torch.empty(32768, dtype=torch.float32, device="cuda")
+print(f"xm_guess_rows on complex128 rows (32768):    {timeit(lambda: dev.guess_rows(x128, N, win, est2, key)):8.1f} us")
+del x128
+key.zero_()
+
+
+def both():
+    dev.guess_rows(x, N, win, est, key)
+    dev.guess_refine(x, N, win, est, key, wkey, hmax, hflat, row)
+
+
+print(f"xm_guess_rows + xm_guess_refine (noise rows: every row is a candidate, 16 per workgroup): {timeit(both):8.1f} us")
 for m in (256, 512, 1024, 2048):
     def coarse_rows(m=m):
         _lib.call("xm_pipeline_fused", x.data_ptr(), nt, None, win.data_ptr(), None, nv, m, 2 * m, 0, FL, norm.data_ptr(),

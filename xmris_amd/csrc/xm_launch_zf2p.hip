@@ -37,6 +37,15 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   static const int chunk_env = getenv("XM_QUEUE_CHUNK") ? atoi(getenv("XM_QUEUE_CHUNK")) : 0;  // tuning switch
   if (chunk_env > 0) chunk = chunk_env;
   chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+  if constexpr ((OPT & ZF2P_QUEUE) == 0) {
+    // static split (the instruction-bound maxima-only passes): as many workgroups as fit the chip, equal shares --
+    // the 96 KiB rule above is the queue's; with 4 KiB rows it left a third of the wave slots empty
+    static const bool even_env = getenv("XM_STATIC_EVEN") == nullptr || atoi(getenv("XM_STATIC_EVEN")) != 0;  // tuning switch
+    if (even_env && chunk_env <= 0) {
+      chunk = (A.n_batch + resident - 1) / resident;
+      chunk = chunk < 1 ? 1 : chunk;
+    }
+  }
   A.queue_chunk = (int)chunk;
   const long long nchunks = (A.n_batch + chunk - 1) / chunk;
   long long blocks = nchunks < resident ? nchunks : resident;
