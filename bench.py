@@ -408,6 +408,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=rccl_group)
         elapsed = float(tmax.item())
 
+    if os.environ.get("XM_BENCH_DEBUG"):  # per-step device times of the timed region (stderr)
+        print("main_ms", [round(v, 3) for v in times["main_ms"]], file=sys.stderr)
+        print("period_ms", [round(v, 3) for v in times["period_ms"]], file=sys.stderr)
+        print("pre_ms", [round(v, 3) for v in times["pre_ms"]], file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nv * args.steps / elapsed
     main_ms = float(np.mean(times["main_ms"]))

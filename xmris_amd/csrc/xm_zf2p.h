@@ -221,6 +221,28 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   long long c_cur = c_first, c_nxt = c_cur + c_step, c_nn = c_nxt + c_step;
   long long s = c_cur * ch;
   unsigned off = 0;  // row within the chunk
+  if constexpr (CAND) {
+    // A workgroup whose best candidate is not among the front runners (estimate below 0.9^2 of the largest one) naps
+    // for about ten microseconds before it starts: by then the front runners have published their exact maxima and
+    // the bound usually rules out everything this workgroup holds (rows of one spectral shape: thousands of
+    // candidates inside the band, one exact transform needed).  s_sleep idles the wave, it does not poll.
+    if (n_rows > 0) {
+      const float* cand_e = reinterpret_cast<const float*>(cand + ZF2P_CAND_CAP);
+      const float top = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cand_e[0])));
+      const float emax2 = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)lds_next[1 + 2 * ZF2P_CAND_CAP + 1]));
+      if (top < 0.81f * emax2) {  // (false for NaN on either side: NaN rows start at once)
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_sleep(127);
+        if (t < XM_WAVE) {
+          const long long nx = next_live(0);
+          if (t == 0u) *lds_next = (unsigned)nx;
+        }
+        __syncthreads();
+        s = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)*lds_next);
+        __syncthreads();
+      }
+    }
+  }
   if (s < n_rows) fetch(rowid(s), e0, coff, n_in);
   if constexpr (QUEUE) {
     if (t == 0) *lds_next = atomicAdd(A.queue, 1u) + gridDim.x;
