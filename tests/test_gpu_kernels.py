@@ -610,12 +610,14 @@ def test_complex128_arg_max_key(dev, n_in, n_out, nb):
 
 def test_phase_ramp_equals_phase_table(dev):
     """xm_pipeline_fused_ramp against xm_pipeline_fused with the table of the same ramp: the native (factorised) path of
-    the hot kernel on every half-length plan, and the expand-to-scratch-table path elsewhere (no zero fill, odd
-    lengths, complex128)."""
+    the hot kernel on every half-length plan and of the two-spectra kernel (no zero fill: powers of two and 3 * 2^k),
+    and the expand-to-scratch-table path elsewhere (5 * 2^k, odd lengths, complex128 without the zero fill)."""
     import torch
 
     for dtype, n_in, n_out, pad in (("complex64", 4096, 8192, 0), ("complex64", 2048, 4096, 0), ("complex64", 1000, 2048, 0),
                                     ("complex64", 400, 1024, 0), ("complex64", 1001, 2048, 0), ("complex64", 1536, 1536, 0),
+                                    ("complex64", 4096, 4096, 0), ("complex64", 3000, 3072, 10), ("complex64", 1280, 1280, 0),
+                                    ("complex64", 700, 768, 0), ("complex64", 6144, 6144, 0),
                                     ("complex64", 1000, 4096, 24), ("complex64", 8192, 16384, 0), ("complex64", 5000, 16384, 100),
                                     ("complex64", 5001, 16384, 0), ("complex128", 4096, 8192, 0), ("complex128", 1972, 1972, 0),
                                     ("complex128", 2048, 4096, 0), ("complex128", 1001, 2048, 3), ("complex128", 400, 1024, 0),
@@ -631,7 +633,9 @@ def test_phase_ramp_equals_phase_table(dev):
         got = dev.pipeline_fused(x, n_out, pad, window=w, phase_ramp=(a, b)).out.cpu().numpy()
         native = dev.ramp_native(x, n_out, pad)
         zf2 = 2 * (pad + n_in) <= n_out and n_out in (1024, 2048, 4096, 8192, 16384)
-        assert native == (zf2 and (dtype == "complex128" or (n_in % 2 == 0 and pad % 2 == 0))), (dtype, n_in, n_out, pad)
+        # ... or, complex64 without the >= 2x zero fill, the two-spectra kernel's plans of at most 16 points per thread
+        fft2 = dtype == "complex64" and not zf2 and n_out in (512, 1024, 2048, 4096, 8192, 768, 1536, 3072, 6144)
+        assert native == ((zf2 and (dtype == "complex128" or (n_in % 2 == 0 and pad % 2 == 0))) or fft2), (dtype, n_in, n_out, pad)
         assert _relerr(got, ref) < (1e-6 if dtype == "complex64" else 1e-13), (dtype, n_in, n_out, pad, native)
 
 

@@ -561,10 +561,10 @@ int xm_pipeline_ramp_native(const void* in, int64_t in_row_stride, int n_in, int
 
 int xm_pipeline_key_native(const void* in, int64_t in_row_stride, int n_in, int n_out, int pad_left, unsigned flags,
                            int dtype) {
-  if (!xm_pipeline_ramp_native(in, in_row_stride, n_in, n_out, pad_left, flags, dtype)) return 0;
-  if (dtype == XM_C64) return 1;
+  if ((dtype != XM_C64 && dtype != XM_C128) || n_in < 1 || pad_left < 0 || pad_left + n_in > n_out) return 0;
+  if (dtype == XM_C64) return xm_key_native_f32(in, in_row_stride, n_in, n_out, pad_left, flags);
   static const bool gen1 = getenv("XM_ZF2D_GEN1") != nullptr;  // (tuning switch: k_zf2<double> has no key)
-  return !gen1 && (n_out == 8192 || n_out == 16384);  // k_zf2d's half lengths
+  return !gen1 && xm_key_native_f64(in, in_row_stride, n_in, n_out, pad_left, flags);
 }
 
 int xm_fft1d_batched(const void* in, void* out, int64_t n_batch, int n, unsigned flags, int dtype, void* stream) {

@@ -48,6 +48,9 @@ bool xm_supported_in_lds(int n, int dtype);
 // 1 when a geometry has a kernel that applies the ramp natively (no table is built), else 0
 int xm_ramp_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 int xm_ramp_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
+// ... and whether it leaves the launch's arg-max in a key (XM_AMAX_GLOBAL_KEY)
+int xm_key_native_f32(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
+int xm_key_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags);
 
 // xm_launch_zf2p.hip: guess stage of the speculative schedule (xm_guess_* in xmris_hip.h)
 int xm_zf2p_guess_supported(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags, int dtype);

@@ -700,8 +700,14 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
   using V = xm_f2;
   constexpr int N = PL::N, NT = PL::NT, P = PL::P;
   constexpr bool WRITE = (MODE & ZF2_WRITE) != 0, PHASE = (MODE & ZF2_PHASE) != 0, AMAX = (MODE & ZF2_AMAX) != 0;
+  // ZF2_RAMP: a linear output phase e^{i (a + b k)} in factorised form, as in k_zf2p: output k of thread t, slot q is
+  // base_q + t with base_q = (NT q + out_shift) mod N a multiple of NT (the launcher checks out_shift % NT == 0), so
+  // e^{i b t} is folded into the last stage's register twiddles once per launch and the wave-uniform e^{i (a + b base_q)}
+  // comes from the kernel arguments -- no table, no per-output load (forward transforms only)
+  constexpr bool RAMP = (MODE & ZF2_RAMP) != 0;
+  static_assert(!(PHASE && RAMP) && (!RAMP || (WRITE && P <= 16)), "a ramp replaces the table of a writing mode; 16 slots");
   using FFT = BlockFFT<V, PL>;
-  using HT = HotTw<T, PL>;
+  using HT = HotTw<T, PL, RAMP>;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
   Cx<T>* mid = reinterpret_cast<Cx<T>*>(lds + FFT::lds_elems());
@@ -716,6 +722,11 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
     for (int i = t; i < HT::mid_size(); i += NT) mid[i] = A.tw[i];
   } else {
     tw.mid = A.tw;
+  }
+  if constexpr (RAMP) {
+    double sn, cs;
+    sincos(A.ramp_db * (double)t, &sn, &cs);
+    tw.fold(mk<T>((T)cs, (T)sn));
   }
   // FFT input position pos = t + NT*q holds padded sample j = (pos - in_shift) mod N = input sample j - pad_left
   T w[P];
@@ -800,8 +811,12 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
         int k = tt + NT * q + osh;
         if (k >= N) k -= N;
         Cx<V> y = v[q];
-        if (A.inverse) y.im = -y.im;
-        if constexpr (PHASE) y = y * A.phase[k];
+        if constexpr (RAMP) {  // (wave-uniform factor of slot q: scalar loads from the kernel-argument segment)
+          y = y * mk<T>(A.ramp_c[2 * q], A.ramp_c[2 * q + 1]);
+        } else {
+          if (A.inverse) y.im = -y.im;
+          if constexpr (PHASE) y = y * A.phase[k];
+        }
         o0[k] = mk<T>(y.re.x, y.im.x);
         if (has1) o1[k] = mk<T>(y.re.y, y.im.y);
       }

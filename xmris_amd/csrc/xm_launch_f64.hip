@@ -13,4 +13,8 @@ int xm_ramp_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, i
   return ramp_native(in, in_stride, n_in, n_out, pad_left, flags) ? 1 : 0;
 }
 
+int xm_key_native_f64(const void* in, int64_t in_stride, int n_in, int n_out, int pad_left, unsigned flags) {
+  return key_native(in, in_stride, n_in, n_out, pad_left, flags) ? 1 : 0;
+}
+
 int xm_big_supported_f64(int n) { return big_supported(n) ? 1 : 0; }
