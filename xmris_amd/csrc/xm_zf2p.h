@@ -297,6 +297,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       v[q].re = V{e.re, o.re};
       v[q].im = V{e.im, o.im};
     });
+    // (round 3, same-box A/B of four builds, main kernel alone: this order 1.067 ms; every wave waiting for the
+    // prefetch right here 1.123; the prefetch issued behind the stores 1.19; the previous row's stores drained before
+    // the prefetch is issued 1.082)
     if constexpr (!CAND) {
       if (s_nxt < n_rows) fetch(rowid(s_nxt), ee0, cc - pl, nin);
     }
