@@ -22,7 +22,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   A.tw = (const Cx<T>*)tw;
   if (A.n_batch <= 0) return XM_OK;
   constexpr bool L16 = (OPT & ZF2P_LOAD16) != 0;
-  using FFT = BlockFFT<xm_f2, PL, L16 ? xm_ilog2(2 * PL::radix(0)) : -1>;
+  using FFT = BlockFFT<xm_f2, PL, zf2p_pad_shift<PL, L16>()>;
   constexpr bool CAND = (OPT & ZF2P_CAND) != 0;
   const size_t lds = (size_t)FFT::lds_elems() * sizeof(Cx<xm_f2>) + (size_t)HotTw<T, PL>::mid_lds_size() * sizeof(Cx<T>) +
                      ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int)) + (CAND ? zf2p_cand_lds_bytes() : 0);

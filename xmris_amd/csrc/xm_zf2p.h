@@ -55,6 +55,16 @@ constexpr int xm_ilog2(int v) {
   return s;
 }
 
+// pad shift of the exchange buffer (one pad element per 2^shift elements; -1: the block FFT's default)
+#ifndef ZF2P_SH8
+#define ZF2P_SH8 4
+#endif
+template <class PL, bool L16>
+constexpr int zf2p_pad_shift() {
+  if (!L16) return -1;
+  return PL::radix(0) == 8 ? ZF2P_SH8 : xm_ilog2(2 * PL::radix(0));
+}
+
 template <class PL, int MODE, int OPT>
 __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeArgs<float> A) {
   using T = float;
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   static_assert(!(PHASE && RAMP), "phase table and ramp are exclusive");
   static_assert(!RAMP || WRITE, "a ramp needs an output");
   static_assert(P % 2 == 0 && NT >= XM_WAVE, "pair loads need an even number of points per thread, whole waves");
-  using FFT = BlockFFT<V, PL, L16 ? xm_ilog2(2 * PL::radix(0)) : -1>;
+  using FFT = BlockFFT<V, PL, zf2p_pad_shift<PL, L16>()>;
   using HT = HotTw<T, PL, RAMP>;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   Cx<V>* lds = reinterpret_cast<Cx<V>*>(xm_smem);
