@@ -221,6 +221,18 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     if plan is None:
         plan = make_plan(x2, t, target_points, lb)
     n = plan.n_out
+    # One dataset, own solve: where the guess stage and the arg-max key apply, the speculative schedule replaces the
+    # FFT pre-pass (0.89 ms on the roofline shape) by coarse spectra + an exact check of the candidates (0.14 ms); the
+    # main pass verifies the guess and a wrong one is repaired -- same result as the classic order below
+    # (XMRIS_AMD_RUN_CLASSIC=1 keeps that order).
+    if (params is None and target_coord is None and os.environ.get("XMRIS_AMD_RUN_CLASSIC") is None
+            and x2.dim() == 2 and x2.is_contiguous() and plan.window is not None
+            and dev.guess_supported(x2, n, plan.pad_left) and dev.key_native(x2, n, plan.pad_left)):
+        if out is None:
+            out = torch.empty((x2.shape[0], n), dtype=x2.dtype, device=x2.device)
+        res = run_stream([x2], [out], plan, method=method, peak_width=peak_width, p0_only=p0_only, speculate=True,
+                         polish=polish)[0]
+        return out, res, plan
     # with a solve, only the winning ROW is needed from the pre-pass (its index along the axis comes from
     # the winning spectrum itself, recomputed in fp64); injected parameters need the full arg-max
     pre = dev.pipeline_fused(x2, n, plan.pad_left, window=plan.window, want_out=False, want_argmax=True,
@@ -239,7 +251,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
 
 def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=None, rank_offset_rows: int = 0,
                overlap: bool = True, method: str = "acme", peak_width=100, target_coord=None, p0_only: bool = False,
-               trace: list | None = None, speculate: bool = False):
+               trace: list | None = None, speculate: bool = False, polish: str = "native"):
     """The fused hot path over a SEQUENCE of independent datasets of one shape, software-pipelined.
 
     ``inputs[i]`` ([n_batch, n_in] complex rows in HBM) is transformed into ``outputs[i]`` ([n_batch, n_out]);
@@ -285,14 +297,14 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
     gc.disable()
     try:
         return _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width,
-                           target_coord, p0_only, trace, speculate)
+                           target_coord, p0_only, trace, speculate, polish)
     finally:
         if gc_was_enabled:
             gc.enable()
 
 
 def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width,
-                target_coord, p0_only, trace, speculate):
+                target_coord, p0_only, trace, speculate, polish="native"):
     import time
 
     import torch
@@ -302,7 +314,7 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
         if target_coord is not None:
             raise ValueError("speculate=True needs the arg-max pivot (target_coord=None)")
         return _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
-                                       peak_width, p0_only, trace)
+                                       peak_width, p0_only, trace, polish)
     n = plan.n_out
     x0 = inputs[0]
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
@@ -351,7 +363,7 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
 
         res, mine = select_and_solve(inputs[i], plan, absmax2[b], argidx[b], method, peak_width, target_coord,
                                      p0_only, exchange=merged, rank_offset_rows=rank_offset_rows,
-                                     on_host_phase=queue_next, selection=sel[b])
+                                     on_host_phase=queue_next, selection=sel[b], polish=polish)
         if broadcast is not None:
             res.p0, res.p1 = broadcast([res.p0, res.p1], owner_box[0])
         res.owner, res.mine = owner_box[0], mine
@@ -395,7 +407,7 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
 
 
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
-                            peak_width, p0_only, trace):
+                            peak_width, p0_only, trace, polish="native"):
     """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair).
 
     Software pipeline over the datasets (with `overlap`): while the main pass of dataset i is queued, the guess
@@ -524,7 +536,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     fill_team = aps.burst_threads()
 
     def search(sl, k, pivot, threads):
-        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads)
+        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads, polish=polish)
 
     pending = {}  # dataset -> (partial result, future or None)
 
@@ -577,7 +589,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                 plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x1.device, torch.float64)
             sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out[0].cpu().numpy()
             k = int(np.argmax(np.abs(sl)))
-            p0, p1, opt = aps.solve(sl, plan.freq, float(plan.freq[k]), k, iw, method=method, p0_only=p0_only)
+            p0, p1, opt = aps.solve(sl, plan.freq, float(plan.freq[k]), k, iw, method=method, p0_only=p0_only, polish=polish)
             vals = [p0, p1, float(k), float(opt.nfev)]
         if broadcast is not None:
             vals = broadcast(vals, owner)
