@@ -188,7 +188,7 @@ def main():
                          "page tables and the software pipeline reach their steady state however short --warmup is)")
     ap.add_argument("--datasets", type=int, default=4,
                     help="distinct synthetic datasets the steps rotate through (different noise, different brightest voxel)")
-    ap.add_argument("--hetero-sets", type=int, default=32,
+    ap.add_argument("--hetero-sets", type=int, default=64,
                     help="footnote: datasets of the heterogeneous family (synth_hetero) the hit rate is measured on")
     ap.add_argument("--no-footnotes", action="store_true",
                     help="skip the extra measurements after the timed region (classic schedule, single dataset, forced "
