@@ -456,7 +456,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     if band is None:
         wabs = np.abs(np.asarray(plan.window_host, dtype=np.float64)[plan.pad_left:plan.pad_left + plan.n_in])
         inside = float(wabs[:512].sum()) / max(float(wabs.sum()), 1e-300)
-        band = plan.extra["guess_band"] = float(min(0.95, max(0.25, 0.9 * inside)))
+        # ... floored at 0.4: the window bound assumes a line that does not decay by itself; measured on the
+        # heterogeneous family WITHOUT apodisation (lb = 0, inside = 0.125): 12/12 hits with 0.25 and with 0.4 (device
+        # period 1.43 / 1.31 ms: a wide band costs exact transforms), 11/12 with 0.5 (scripts/time_hetero_lb.py)
+        band = plan.extra["guess_band"] = float(min(0.95, max(0.4, 0.9 * inside)))
     if os.environ.get("XM_GUESS_BAND"):  # tuning switch
         band = float(os.environ["XM_GUESS_BAND"])
     l1_keys = use_keys and not c128 and not use_guess  # round 2's guess stage leaves its winner in a key (complex64)
