@@ -203,6 +203,9 @@ def main():
         try:
             dt0 = 1.0 / 5000.0
             cpu_pool = CpuPool(min(16384, args.voxels), args.n_time, np.arange(args.n_time) * dt0, args.target_points, args.lb)
+            import atexit
+
+            atexit.register(cpu_pool.close)  # (whatever happens below: the workers and the shared block go away)
         except Exception as e:  # noqa: BLE001
             print(f"all-cores CPU baseline unavailable: {e!r}", file=sys.stderr)
 
@@ -771,9 +774,12 @@ class CpuPool:
         }
 
     def close(self):
-        for _ in self.procs:
+        if self.procs is None:
+            return
+        procs, self.procs = self.procs, None
+        for _ in procs:
             self.tasks.put(None)
-        for p in self.procs:
+        for p in procs:
             p.join(timeout=10)
         try:
             self.shm.close()

@@ -47,7 +47,11 @@
 enum { ZF2P_LOAD16 = 1, ZF2P_NT = 2, ZF2P_QUEUE = 8, ZF2P_EST = 16, ZF2P_CAND = 32, ZF2P_IN64 = 64 };  // OPT bits
 constexpr int ZF2P_CAND_CAP = 16;      // candidates one workgroup transforms at most
 constexpr int ZF2P_CAND_KMAX = 16384;  // row blocks (of gridDim.x rows each) one workgroup can scan: bits of its LDS bitmap
-constexpr size_t zf2p_cand_lds_bytes() { return (2 * ZF2P_CAND_CAP + 3 + ZF2P_CAND_KMAX / 32) * sizeof(unsigned); }
+// LDS words of the refine stage behind the workgroup's ticket word `lds_next`: [1, CAP] candidate rows, (CAP, 2 CAP]
+// their estimates (descending), then the count, the largest estimate of the launch (float bits) and the scan's bitmap
+constexpr int ZF2P_CAND_ROWS = 1, ZF2P_CAND_EST = 1 + ZF2P_CAND_CAP, ZF2P_CAND_COUNT = 1 + 2 * ZF2P_CAND_CAP,
+              ZF2P_CAND_TOP = ZF2P_CAND_COUNT + 1, ZF2P_CAND_BITMAP = ZF2P_CAND_TOP + 1;
+constexpr size_t zf2p_cand_lds_bytes() { return (ZF2P_CAND_BITMAP + ZF2P_CAND_KMAX / 32) * sizeof(unsigned); }
 
 constexpr int xm_ilog2(int v) {
   int s = 0;
@@ -98,13 +102,13 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
 
   // rows this workgroup iterates over: all of the launch's (static stride or the queue), or its own candidates
   long long n_rows = A.n_batch;
-  unsigned* cand = lds_next + 1;
+  unsigned* cand = lds_next + ZF2P_CAND_ROWS;
   const unsigned n_in = (unsigned)A.n_in;
   if constexpr (CAND) {
-    float* cand_e = reinterpret_cast<float*>(cand + ZF2P_CAND_CAP);  // their estimates, descending
-    unsigned* cand_n = cand + 2 * ZF2P_CAND_CAP;
-    unsigned* top_bits = cand_n + 1;
-    unsigned* bitmap = top_bits + 1;
+    float* cand_e = reinterpret_cast<float*>(lds_next + ZF2P_CAND_EST);
+    unsigned* cand_n = lds_next + ZF2P_CAND_COUNT;
+    unsigned* top_bits = lds_next + ZF2P_CAND_TOP;
+    unsigned* bitmap = lds_next + ZF2P_CAND_BITMAP;
     const unsigned G = gridDim.x, b = blockIdx.x;
     const unsigned kmax = (unsigned)((A.n_batch + G - 1) / G);  // <= ZF2P_CAND_KMAX (checked by the launcher)
     for (unsigned i = t; i < (kmax + 31u) / 32u; i += NT) bitmap[i] = 0u;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
   // CAND: the first candidate at or behind v that the best exact maximum found so far (by any workgroup) does not rule out
   auto next_live = [&](long long v) -> long long {
     if constexpr (CAND) {
-      const float* cand_e = reinterpret_cast<const float*>(cand + ZF2P_CAND_CAP);
+      const float* cand_e = reinterpret_cast<const float*>(lds_next + ZF2P_CAND_EST);
       // (64 partial bounds on cache lines of their own, like the keys: one address takes ~90 atomics per microsecond)
       const unsigned gb = wave_reduce_u32<true>(__hip_atomic_load(A.gbest + lane * (2u * XM_KEY_STRIDE), __ATOMIC_RELAXED,
                                                                   __HIP_MEMORY_SCOPE_AGENT));
@@ -238,9 +242,9 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
     // the bound usually rules out everything this workgroup holds (rows of one spectral shape: thousands of
     // candidates inside the band, one exact transform needed).  s_sleep idles the wave, it does not poll.
     if (n_rows > 0) {
-      const float* cand_e = reinterpret_cast<const float*>(cand + ZF2P_CAND_CAP);
+      const float* cand_e = reinterpret_cast<const float*>(lds_next + ZF2P_CAND_EST);
       const float top = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cand_e[0])));
-      const float emax2 = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)lds_next[1 + 2 * ZF2P_CAND_CAP + 1]));
+      const float emax2 = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)lds_next[ZF2P_CAND_TOP]));
       if (top < 0.81f * emax2) {  // (false for NaN on either side: NaN rows start at once)
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) __builtin_amdgcn_s_sleep(127);

@@ -82,7 +82,6 @@ def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end
 
     # ---- upload || pre-pass ---------------------------------------------------------------------
     pool = _pool()
-    free = [None] * len(stage)  # event after which staging buffer k may be refilled
     fills = {}
 
     def fill(k, lo_b, n_b):
@@ -98,7 +97,6 @@ def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end
             dst_bytes[lo * row_bytes:lo * row_bytes + n_b].copy_(stage[k][:n_b], non_blocking=True)
             landed = torch.cuda.Event()
             landed.record(copy_in)
-        free[k] = landed
         j = i + len(stage)
         if j < len(chunks):  # refill this staging buffer once its DMA is done (the worker waits, not this thread)
             lo2, hi2 = chunks[j]
