@@ -652,14 +652,15 @@ def c128_note(torch, pipeline, xs, t, N, args, speculate):
     main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
     bytes2 = 16 * (x2[0].shape[1] + N) * nv
     hot = (x2[0].shape[1], N) == (4096, 8192)
+    kernel2 = (("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
+                else "xm_pipeline_fused_ramp main pass")
+               + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")"))
+    traffic2, source2 = pmc_traffic("c128", kernel2, nv, x2[0].shape[1], N)
     return {"voxels": nv, "steps": k2, "value": nv / (ms2 * 1e-3), "ms_per_step": ms2, "dtype": "f64",
-            "roofline": {"bound": "hbm",
-                         "kernel": ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
-                                   else "xm_pipeline_fused_ramp main pass")
-                                   + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")"),
+            "roofline": {"bound": "hbm", "kernel": kernel2,
                          "achieved": bytes2 / (main2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes2,
-                         "avg_launch_ms": main2, "traffic": None},
+                         "avg_launch_ms": main2, "traffic": traffic2, "traffic_source": source2},
             "main_kernel_ms": main2, "main_kernel_frac": bytes2 / (main2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "end_to_end_roofline_frac": nv / (ms2 * 1e-3) * 16 * (x2[0].shape[1] + N) / 1e9 / HBM_PEAK_GBPS,
             "speculation": ({"hit": sum(r.speculation == "hit" for r in res),
