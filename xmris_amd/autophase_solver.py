@@ -131,8 +131,8 @@ def default_threads() -> int:
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     if local_world > 1:
         # Several ranks on one node share its cores.  Searches are per DATASET, not per rank: only the rank that owns
-        # a dataset's winning spectrum searches, the streaming executor keeps two searches in flight on the whole node
-        # (`pipeline._run_stream_speculative`: look-ahead 2 with an exchange), and the other ranks wait for the
+        # a dataset's winning spectrum searches, the streaming executor keeps its look-ahead's worth of searches (two to four)
+        # in flight on the whole node (`pipeline._run_stream_speculative`), and the other ranks wait for the
         # broadcast sleep-polling.  So the node-wide budget is what the ranks' launch threads leave: one core per rank
         # is reserved for launching and polling (a launch thread is busy for ~0.2 ms of a 1.2 ms step), the searches
         # in flight share the rest -- 16 CPUs and 8 ranks: 8 cores, 4 per search (1.1 ms of generations; round 2's

@@ -431,8 +431,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     workers, team = _search_workers(plan, nb, x0.element_size(), aps.default_threads())
     if exchange is not None:
         # several ranks: the look-ahead fixes the ORDER of the exchange calls, which every rank must make alike --
-        # it may not depend on anything a rank measures or owns (its shard size, its share of the host's cores)
-        workers = 2
+        # it may not depend on anything a rank measures or owns (its shard size, its share of the host's cores).
+        # Rank 0's choice goes to everyone (one more broadcast at the start of the call); without a broadcast
+        # callable: two.
+        workers = int(round(broadcast([float(workers)], 0)[0])) if broadcast is not None else 2
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     # (round 3: the selection stage of dataset j on a stream of its own beside the coarse spectra of dataset j + 1,
     # gated so that it never shares the chip with a main pass, hides nothing -- the coarse-spectra kernel fills the
