@@ -545,3 +545,30 @@ def test_restated_xarray_semantics_one_by_one(monkeypatch):
     ref_p0 = __import__("xmris_amd.autophase_solver", fromlist=["solve"]).solve(
         y[1].astype(np.complex128), t - 1.0, (t - 1.0)[4], 4, 1, p0_only=True, polish="numpy")[0]
     assert got.attrs["phase_p0"] == ref_p0  # ... and the search ran on row 1 (the slice isel would return), not row 0
+
+
+def test_solver_team_budget(monkeypatch):
+    """`default_threads` / `burst_threads` / `scarce_cpus`: one rank takes half of its CPU share (power of two, at most
+    16) and the whole share for a lone search; several ranks on a node reserve one core per rank and give the rest to
+    the searches in flight on the node (16 CPUs, 8 ranks: 8 -- round 2's rule left one thread); few cores per rank ->
+    blocking event waits."""
+    from xmris_amd import autophase_solver as aps
+
+    for var in ("XM_SOLVER_THREADS", "XM_BLOCKING_SYNC", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    share = {"n": 16}
+    monkeypatch.setattr(aps, "_cpu_share", lambda: share["n"])
+    assert (aps.default_threads(), aps.burst_threads(), aps.scarce_cpus()) == (8, 16, False)
+    share["n"] = 6
+    assert (aps.default_threads(), aps.burst_threads()) == (2, 4)
+    share["n"] = 256
+    assert (aps.default_threads(), aps.burst_threads()) == (16, 16)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    share["n"] = 16
+    assert (aps.default_threads(), aps.burst_threads(), aps.scarce_cpus()) == (8, 8, True)
+    share["n"] = 128
+    assert (aps.default_threads(), aps.scarce_cpus()) == (16, False)
+    share["n"] = 8
+    assert aps.default_threads() == 1  # (never zero)
+    monkeypatch.setenv("XM_SOLVER_THREADS", "5")
+    assert aps.default_threads() == aps.burst_threads() == 5

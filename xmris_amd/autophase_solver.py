@@ -110,24 +110,13 @@ def scarce_cpus() -> bool:
 
 
 def default_threads() -> int:
-    """Team size for the native objective: a power of two, at most 16 and at most HALF of this process's share of
-    the CPUs it may use (scheduler affinity and the cgroup v2 quota, divided by the ranks torchrun started on
-    this node)."""
+    """Team size for the native objective: at most 16 and at most HALF of this process's share of the CPUs it may use
+    (scheduler affinity and the cgroup v2 quota), as a power of two; several ranks on one node: see below."""
     import os
 
     if os.environ.get("XM_SOLVER_THREADS"):  # tuning switch
         return max(1, min(32, int(os.environ["XM_SOLVER_THREADS"])))
-    try:
-        cpus = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cpus = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            cpus = min(cpus, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
+    cpus = _cpu_share()
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     if local_world > 1:
         # Several ranks on one node share its cores.  Searches are per DATASET, not per rank: only the rank that owns
@@ -141,9 +130,7 @@ def default_threads() -> int:
         return max(1, min(16, cpus - local_world))
     # Half of the share, as a power of two (the work units of a batch are 4 evaluations x 4 parts): a team that
     # fills the whole CPU quota while it spins leaves no headroom for the HIP runtime's threads, and a cgroup that
-    # overdraws its quota is frozen until the next 100 ms period -- measured as rare 15-25 ms stalls of the whole
-    # pipeline with 16 threads on a 16-CPU share, none with 8 (the search takes 0.95 instead of 0.71 ms, still
-    # hidden behind the device).
+    # overdraws its quota is frozen until the next 100 ms period.
     share = max(1, cpus // 2)
     team = 1
     while team * 2 <= min(16, share):
@@ -152,24 +139,15 @@ def default_threads() -> int:
 
 
 def burst_threads() -> int:
-    """Team size for ONE search with nothing beside it (a single accessor call: the device waits for it, no other
-    search runs): the whole share of the CPUs this process may use, up to 16 -- `default_threads` keeps half of it
-    free because a streaming executor's teams spin for as long as it runs; a millisecond does not reach the quota."""
+    """Team size for ONE search with nothing beside it (a single accessor call, or the search that fills a streaming
+    call's pipeline: the device waits for it): the whole share of the CPUs this process may use, up to 16 --
+    `default_threads` keeps half of it free because a streaming executor's teams spin for as long as it runs; a
+    millisecond does not reach the quota."""
     import os
 
     if os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
         return default_threads()
-    try:
-        cpus = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cpus = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            cpus = min(cpus, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
+    cpus = _cpu_share()
     team = 1
     while team * 2 <= min(16, cpus):
         team *= 2

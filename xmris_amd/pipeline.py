@@ -442,12 +442,20 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     ring = g_ahead + 2
     distinct = list({id(x): x for x in inputs}.values())
+
+    def geometry(x):  # (key_native, guess_supported) of a dataset: they depend on its alignment, shape and dtype only
+        k = ("geometry", x.data_ptr() & 15, tuple(x.shape), str(x.dtype), x.is_contiguous())
+        g = plan.extra.get(k)
+        if g is None:
+            g = plan.extra[k] = (dev.key_native(x, plan.n_out, plan.pad_left), dev.guess_supported(x, plan.n_out, plan.pad_left))
+        return g
+
     # the main pass leaves its true global arg-max in a key (no per-row arrays): every dataset must take that kernel
-    use_keys = all(dev.key_native(x, plan.n_out, plan.pad_left) for x in distinct)
+    use_keys = all(geometry(x)[0] for x in distinct)
     c128 = x0.dtype == torch.complex128
     # guess stage: coarse spectra + exact check of the candidates (both precisions); else the windowed L1 norm's winner
     use_guess = (os.environ.get("XM_GUESS_L1") is None and plan.window is not None
-                 and all(dev.guess_supported(x, plan.n_out, plan.pad_left) for x in distinct))
+                 and all(geometry(x)[1] for x in distinct))
     # Candidate band of the guess stage.  A coarse spectrum (first 512 samples, 1024 bins) underestimates a line's height
     # by the part of its windowed FID beyond sample 512 -- at most the window's own weight out there, for a line that
     # does not decay by itself -- and by the grid's scalloping (>= 0.9 for a 2x zero-filled truncated line): rows whose
