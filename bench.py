@@ -391,17 +391,26 @@ def main():
     gc.freeze()
     if args.prime_ms > 0:  # untimed: until the wall clock says the device has been busy for a while
         t_prime = time.perf_counter()
+        best, last_batch = float("inf"), float("inf")
         while True:
             # every run_steps is a sequence of exchanges: all ranks must make the SAME number of calls, so rank 0's
-            # clock decides for everyone (each rank reading its own clock left them one call apart -- a deadlock)
-            go = (time.perf_counter() - t_prime) * 1e3 < args.prime_ms
+            # clock decides for everyone (each rank reading its own clock left them one call apart -- a deadlock).
+            # Past prime_ms the priming goes on (to at most 6 x prime_ms) while the last batch was still more than 4 %
+            # slower than the best one seen: a first process on a fresh box (clocks, page cache, thread pools) settles
+            # within the untimed part instead of inside the K timed steps.
+            spent = (time.perf_counter() - t_prime) * 1e3
+            go = spent < args.prime_ms or (last_batch > 1.04 * best and spent < 6 * args.prime_ms)
             if dist is not None:
                 flag = torch.tensor([1 if go else 0], dtype=torch.int32)
                 dist.broadcast(flag, src=0, group=host_group)
                 go = bool(flag.item())
             if not go:
                 break
+            t_b = time.perf_counter()
             run_steps(8, False)
+            torch.cuda.synchronize()
+            last_batch = time.perf_counter() - t_b
+            best = min(best, last_batch)
     if args.warmup:
         run_steps(args.warmup, False)
     barrier()
