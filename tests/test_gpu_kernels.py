@@ -33,7 +33,7 @@ def _relerr(got, ref):
 
 POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
 MIXED = [384, 768, 1536, 3072, 6144, 640, 1280, 2560, 5120]
-BLUESTEIN = [3, 5, 7, 17, 100, 1000, 1531, 2000, 2049, 4095]
+BLUESTEIN = [3, 5, 7, 17, 100, 1000, 1531, 2000, 2049, 4095, 6000, 8191]  # the last two: chirp-z with M = 16384
 
 
 # beyond the in-LDS plans: four-step over global memory (n = n1 n2), and chirp-z on top of it for everything else
@@ -180,6 +180,8 @@ CASES = [
     (3, 12000, 32768, 100),  # four-step 128 x 256, left pad
     (2, 9000, 20000, 0),   # no two-factor split: chirp-z on top of the four-step (M = 65536)
     (2, 12288, 12288, 0),  # 3 * 2^12 = 8 x 1536
+    (3, 12000, 16384, 50),  # 16384 without the >= 2x zero fill: one in-LDS transform (complex128: plane-by-plane exchange)
+    (3, 5000, 6000, 100),   # chirp-z with M = 16384
 ]
 
 
@@ -202,7 +204,7 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     rd = torch.float32 if dtype == "complex64" else torch.float64
     wd = torch.from_numpy(w).to("cuda", rd)
     phd = torch.from_numpy(ph).to("cuda", xd.dtype)
-    tol = TIGHT[dtype] * (4 if n_out in (1531, 1972, 1000, 3001, 16384, 32768, 20000, 12288) else 1)
+    tol = TIGHT[dtype] * (4 if n_out in (1531, 1972, 1000, 3001, 6000, 16384, 32768, 20000, 12288) else 1)
     # (1) arg-max pre-pass only
     pre = dev.pipeline_fused(xd, n_out, pad_left, window=wd, want_out=False, want_argmax=True)
     amax, flat = dev.argmax_reduce(pre.absmax2, pre.argidx, n_out)

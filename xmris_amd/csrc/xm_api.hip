@@ -42,8 +42,8 @@ bool xm_has_direct_plan(int n, int dtype) {
     XM_PLANS_POW2(XM_CASE)
     XM_PLANS_OTHER(XM_CASE)
     return true;
-    XM_PLANS_C64_ONLY(XM_CASE)
-    return dtype == XM_C64;
+    XM_PLANS_C64_ONLY(XM_CASE)  // 16384: complex128 has a plan of its own (Plan16kD)
+    return true;
 #undef XM_CASE
     default:
       return false;
@@ -60,7 +60,7 @@ bool xm_supported_in_lds(int n, int dtype) {
   if (n < 2) return false;
   if (xm_has_direct_plan(n, dtype)) return true;
   const int m = xm_bluestein_m(n);
-  return xm_has_pow2_plan(m, dtype) || (m == 16384 && dtype == XM_C64);
+  return xm_has_pow2_plan(m, dtype) || m == 16384;
 }
 
 bool xm_supported(int n, int dtype) {

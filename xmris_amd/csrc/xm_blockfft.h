@@ -146,8 +146,14 @@ struct BlockFFT {
     }
     return xm_pad_shift((int)sizeof(Cx<V>));
   }
-  static constexpr int SH = SH_OVERRIDE >= 0 ? SH_OVERRIDE : r0_shift();
-  static constexpr int lds_elems() { return K > 1 ? (N + (N >> SH)) : 0; }
+  // SPLIT: the padded exchange buffer of whole complex elements would not fit the 160 KiB LDS (complex128 16384:
+  // 256 KiB), so the exchange goes through ONE plane of real numbers twice -- real parts, then imaginary parts (the
+  // two are independent registers): half the buffer for twice the barriers.
+  static constexpr bool SPLIT =
+      SH_OVERRIDE < 0 && K > 1 && (long long)(N + (N >> r0_shift())) * (long long)sizeof(Cx<V>) > 160LL * 1024;
+  static constexpr int SH = SPLIT ? xm_pad_shift((int)sizeof(V)) : (SH_OVERRIDE >= 0 ? SH_OVERRIDE : r0_shift());
+  // in units of Cx<V> (SPLIT: a plane of N padded V's)
+  static constexpr int lds_elems() { return K > 1 ? (SPLIT ? (N + (N >> SH) + 1) / 2 : (N + (N >> SH))) : 0; }
 
   template <int ST, int U, int R1, int R, class TW>
   XM_DEV static void twiddle_row(Cx<V>* a, const TW& tw, int k) {
@@ -183,7 +189,7 @@ struct BlockFFT {
         twiddle_row<ST, U, 1, R>(a, tw, k);
       }
       Dft<V, R>::run(a);
-      if constexpr (last) {
+      if constexpr (last || SPLIT) {  // SPLIT: exchange_plane scatters the outputs, one component at a time
 #pragma unroll
         for (int r = 0; r < R; ++r) v[U + PR * r] = a[r];
       } else {
@@ -201,6 +207,39 @@ struct BlockFFT {
     }
   }
 
+  // SPLIT exchange of component C (0 = re, 1 = im) after stage ST: scatter from the butterfly layout left in v,
+  // gather back in the strided layout; leaves the plane free for the next component / stage
+  template <int ST, int C>
+  XM_DEV static void exchange_plane(Cx<V> (&v)[P], V* plane, int t, int t0) {
+    constexpr int R = PL::radix(ST);
+    constexpr int Ns = PL::ns(ST);
+    constexpr int PR = P / R;
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+      const int b = (ST == 0 ? t0 : t) + NT * u;
+      const int o = (b / Ns) * (Ns * R) + (b % Ns);
+      if constexpr (PL::pow2()) {  // per-lane base + immediate offsets, as in butterflies()
+        V* wp = plane + xm_pad<SH>(o);
+#pragma unroll
+        for (int r = 0; r < R; ++r) wp[r * Ns + ((r * Ns) >> SH)] = C ? v[u + PR * r].im : v[u + PR * r].re;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) plane[xm_pad<SH>(o + r * Ns)] = C ? v[u + PR * r].im : v[u + PR * r].re;
+      }
+    }
+    __syncthreads();
+    const V* rp = plane + (PL::pow2() ? xm_pad<SH>(t) : 0);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const V x = PL::pow2() ? rp[NT * q + ((NT * q) >> SH)] : plane[xm_pad<SH>(t + NT * q)];
+      if constexpr (C)
+        v[q].im = x;
+      else
+        v[q].re = x;
+    }
+    __syncthreads();
+  }
+
   struct NoHook {
     XM_DEV void operator()() const {}
   };
@@ -211,7 +250,13 @@ struct BlockFFT {
   XM_DEV static void stage(Cx<V> (&v)[P], Cx<V>* lds, const TW& tw, int t, int t0, const HOOK& hook) {
     constexpr bool last = (ST == K - 1);
     butterflies<ST, 0>(v, lds, tw, t, t0);
-    if constexpr (!last) {
+    if constexpr (!last && SPLIT) {
+      if constexpr (ST == K - 2) hook();
+      V* plane = reinterpret_cast<V*>(lds);
+      exchange_plane<ST, 0>(v, plane, t, t0);
+      exchange_plane<ST, 1>(v, plane, t, t0);
+      stage<ST + 1>(v, lds, tw, t, t0, hook);
+    } else if constexpr (!last) {
       if constexpr (ST == K - 2) hook();
       __syncthreads();
       if constexpr (PL::pow2()) {

@@ -938,6 +938,9 @@ __global__ __launch_bounds__(PL::NT, (fft1_waves<T, PL>())) void k_fft1(PipeArgs
 template <class T, class PL, int SPB>
 __global__ __launch_bounds__(PL::NT* SPB) void k_bluestein(PipeArgs<T> A) {
   constexpr int M = PL::N, NT = PL::NT, P = PL::P;
+  // 1024-thread workgroups have 128 VGPRs per thread: the scheduler must not hoist the table loads of all P positions
+  // in front of the arithmetic (complex128 M = 16384: 34 spilled registers without the fences, 13 with them)
+  constexpr bool FENCE = (NT * SPB >= 1024) && (P * (int)sizeof(Cx<T>) >= 256);
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   const int t = threadIdx.x % NT;
   const int ls = threadIdx.x / NT;
@@ -964,12 +967,24 @@ __global__ __launch_bounds__(PL::NT* SPB) void k_bluestein(PipeArgs<T> A) {
       }
     }
     v[q] = x;
+    if constexpr (FENCE) {
+      if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
   }
   BlockFFT<T, PL>::run(v, lds, A.tw, t);
 #pragma unroll
-  for (int q = 0; q < P; ++q) v[q] = conj(v[q] * A.aux2[t + NT * q]);  // conj -> inverse via forward
+  for (int q = 0; q < P; ++q) {
+    v[q] = conj(v[q] * A.aux2[t + NT * q]);  // conj -> inverse via forward
+    if constexpr (FENCE) {
+      if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   if constexpr (PL::K > 1) __syncthreads();
-  BlockFFT<T, PL>::run(v, lds, A.tw, t);
+  // the second transform reads its twiddles again: with the same pointer the compiler keeps the first transform's
+  // twiddle registers alive for it (complex128 M = 16384: 117 spilled VGPRs, stored in one FFT and reloaded in the other)
+  const Cx<T>* tw2 = A.tw;
+  asm volatile("" : "+s"(tw2));
+  BlockFFT<T, PL>::run(v, lds, tw2, t);
 
   T bv = T(-1);
   int bi = 0x7fffffff;
@@ -987,6 +1002,9 @@ __global__ __launch_bounds__(PL::NT* SPB) void k_bluestein(PipeArgs<T> A) {
         if (A.phase) x = x * A.phase[k];
         if (live) orow[k] = x;
       }
+    }
+    if constexpr (FENCE) {
+      if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (A.absmax2) {

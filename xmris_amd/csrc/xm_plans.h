@@ -45,9 +45,13 @@
   X(2560, 128, 20, 4, 4, 4, 2) \
   X(5120, 256, 20, 4, 4, 4, 4)
 
-// complex64 only: 16384 x 16 B does not fit the 160 KiB LDS
+// 16384, complex64: 128 KiB of exchange buffer
 #define XM_PLANS_C64_ONLY(X) X(16384, 1024, 16, 16, 16, 4)
-
+// 16384, complex128: 16384 x 16 B does not fit the 160 KiB LDS -- the exchange goes through one plane of doubles,
+// real parts then imaginary parts (BlockFFT::SPLIT); radix 8 keeps 1024 threads within their 128 VGPRs
+struct Plan16kD {
+  using type = FftPlan<16384, 1024, 8, 8, 8, 8, 4>;
+};
 template <int N>
 struct PlanOf;
 #define XM_DEF_PLAN(N, NT, ...)               \
