@@ -50,9 +50,11 @@ bool xm_has_direct_plan(int n, int dtype) {
   }
 }
 
-int xm_bluestein_m(int n) {  // smallest power of two >= max(2n-1, 16)
+int xm_bluestein_m(int n) {  // smallest convolution length with a plan >= max(2n-1, 16): 2^k, or 3 * 2^k where built
   int m = 16;
   while (m < 2 * n - 1) m <<= 1;
+  static const bool pow2_only = getenv("XM_BLUE_POW2") != nullptr;  // tuning switch
+  if (!pow2_only && m == 4096 && 2 * n - 1 <= 3072) return 3072;
   return m;
 }
 
@@ -60,7 +62,7 @@ bool xm_supported_in_lds(int n, int dtype) {
   if (n < 2) return false;
   if (xm_has_direct_plan(n, dtype)) return true;
   const int m = xm_bluestein_m(n);
-  return xm_has_pow2_plan(m, dtype) || m == 16384;
+  return xm_has_pow2_plan(m, dtype) || m == 16384 || m == 3072;
 }
 
 bool xm_supported(int n, int dtype) {

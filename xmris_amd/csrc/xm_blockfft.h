@@ -47,6 +47,8 @@ struct FftPlan {
     return o;
   }
   static constexpr int tw_size() { return tw_offset(K); }
+  // distinguishes the plans of one length in the table cache: threads, stage count and the first two radices
+  static constexpr int signature() { return NT | (K << 12) | (radix(0) << 16) | ((K > 1 ? radix(1) : 0) << 24); }
   static constexpr bool valid() {
     int p = 1;
     for (int j = 0; j < K; ++j) {
@@ -62,6 +64,13 @@ struct FftPlan {
   // (lane part + compile-time part) splits into a per-lane base plus an immediate offset
   static constexpr bool pow2() {
     for (int j = 0; j < K; ++j)
+      if (radix(j) & (radix(j) - 1)) return false;
+    return (NT & (NT - 1)) == 0;
+  }
+  // the same for every stage that SCATTERS (all but the last, whose outputs stay in registers): a plan that keeps its
+  // odd factor for the last stage (4.4.4.4.20) addresses the LDS like a power-of-two plan
+  static constexpr bool scatter_pow2() {
+    for (int j = 0; j + 1 < K; ++j)
       if (radix(j) & (radix(j) - 1)) return false;
     return (NT & (NT - 1)) == 0;
   }
@@ -194,7 +203,7 @@ struct BlockFFT {
         for (int r = 0; r < R; ++r) v[U + PR * r] = a[r];
       } else {
         const int o = (b / Ns) * (Ns * R) + (b % Ns);
-        if constexpr (PL::pow2()) {  // o has zero bits where r*Ns lives: pad(o + c) = pad(o) + pad(c)
+        if constexpr (PL::scatter_pow2()) {  // o has zero bits where r*Ns lives: pad(o + c) = pad(o) + pad(c)
           Cx<V>* wp = lds + xm_pad<SH>(o);
 #pragma unroll
           for (int r = 0; r < R; ++r) wp[r * Ns + ((r * Ns) >> SH)] = a[r];
@@ -218,7 +227,7 @@ struct BlockFFT {
     for (int u = 0; u < PR; ++u) {
       const int b = (ST == 0 ? t0 : t) + NT * u;
       const int o = (b / Ns) * (Ns * R) + (b % Ns);
-      if constexpr (PL::pow2()) {  // per-lane base + immediate offsets, as in butterflies()
+      if constexpr (PL::scatter_pow2()) {  // per-lane base + immediate offsets, as in butterflies()
         V* wp = plane + xm_pad<SH>(o);
 #pragma unroll
         for (int r = 0; r < R; ++r) wp[r * Ns + ((r * Ns) >> SH)] = C ? v[u + PR * r].im : v[u + PR * r].re;
@@ -228,10 +237,10 @@ struct BlockFFT {
       }
     }
     __syncthreads();
-    const V* rp = plane + (PL::pow2() ? xm_pad<SH>(t) : 0);
+    const V* rp = plane + (PL::scatter_pow2() ? xm_pad<SH>(t) : 0);
 #pragma unroll
     for (int q = 0; q < P; ++q) {
-      const V x = PL::pow2() ? rp[NT * q + ((NT * q) >> SH)] : plane[xm_pad<SH>(t + NT * q)];
+      const V x = PL::scatter_pow2() ? rp[NT * q + ((NT * q) >> SH)] : plane[xm_pad<SH>(t + NT * q)];
       if constexpr (C)
         v[q].im = x;
       else
@@ -259,7 +268,7 @@ struct BlockFFT {
     } else if constexpr (!last) {
       if constexpr (ST == K - 2) hook();
       __syncthreads();
-      if constexpr (PL::pow2()) {
+      if constexpr (PL::scatter_pow2()) {
         const Cx<V>* rp = lds + xm_pad<SH>(t);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = rp[NT * q + ((NT * q) >> SH)];

@@ -15,7 +15,7 @@ using T = double;
 template <class PL, int MODE>
 int launch_mode(PipeArgs<T> A, hipStream_t st) {
   const void* tw = nullptr;
-  int rc = xm_table_get(TK_TWIDDLE, PL::N, PL::NT, XM_C128, xm_gen_twiddles<PL>, nullptr, &tw);
+  int rc = xm_table_get(TK_TWIDDLE, PL::N, PL::signature(), XM_C128, xm_gen_twiddles<PL>, nullptr, &tw);
   if (rc) return rc;
   A.tw = (const Cx<T>*)tw;
   if (A.n_batch <= 0) return XM_OK;

@@ -30,20 +30,26 @@
 // shapes above (two spectra per lane pair double the per-thread state), plus 8192
 #define XM_PLANS_FFT2_EXTRA(X) X(8192, 1024, 8, 8, 8, 8, 2)
 
-// tiny lengths and 3*2^k / 5*2^k lengths: generic kernel only
+// tiny lengths and 3*2^k / 5*2^k lengths.  Where the odd factor rides in the LAST stage (12 or 20 points per thread,
+// whose outputs stay in registers) every stage that scatters through the LDS has power-of-two geometry: shifts and
+// masks instead of divisions by 20 / 80 / ..., one per-lane base plus immediate offsets (FftPlan::scatter_pow2) -- at
+// the price of 11 / 19 last-stage twiddles held in registers.  Measured both ways on one box (round 3, TB/s of the
+// staged seam, complex64 / complex128; odd factor first -> last): 2560 2.9 -> 4.1 / 2.9 -> 4.9, 5120 2.8 -> 3.8 /
+// 3.0 -> 4.5, 6144 3.9 -> 4.3 / 4.1 -> 4.8, 384 and 640 +4 %; 768, 1280, 1536 and 3072 lose 2-10 % and keep the
+// odd factor first.
 #define XM_PLANS_OTHER(X)     \
   X(2, 1, 2)                  \
   X(4, 1, 4)                  \
   X(8, 1, 8)                  \
-  X(384, 16, 24, 4, 4)        \
+  X(384, 16, 4, 4, 24)        \
   X(768, 64, 12, 4, 4, 4)     \
   X(1536, 128, 12, 4, 4, 4, 2) \
   X(3072, 256, 12, 4, 4, 4, 4) \
-  X(6144, 512, 12, 4, 4, 4, 4, 2) \
-  X(640, 32, 20, 4, 4, 2)     \
+  X(6144, 512, 4, 4, 4, 4, 2, 12) \
+  X(640, 32, 4, 4, 2, 20)     \
   X(1280, 64, 20, 4, 4, 4)    \
-  X(2560, 128, 20, 4, 4, 4, 2) \
-  X(5120, 256, 20, 4, 4, 4, 4)
+  X(2560, 128, 4, 4, 4, 2, 20) \
+  X(5120, 256, 4, 4, 4, 4, 20)
 
 // 16384, complex64: 128 KiB of exchange buffer
 #define XM_PLANS_C64_ONLY(X) X(16384, 1024, 16, 16, 16, 4)
