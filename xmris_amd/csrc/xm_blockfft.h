@@ -77,6 +77,17 @@ struct FftPlan {
 };
 
 
+// The same plan with the plane-by-plane exchange forced (BlockFFT::SPLIT): half the exchange buffer, i.e. room for a
+// second workgroup on the CU, for twice the barriers
+template <class PL>
+struct SplitPlan : PL {
+  static constexpr bool kForceSplit = true;
+};
+template <class PL, class = void>
+struct xm_force_split : std::false_type {};
+template <class PL>
+struct xm_force_split<PL, typename std::enable_if<PL::kForceSplit>::type> : std::true_type {};
+
 // Twiddle sources.  get<S, U, R_IDX>(k): twiddle of stage S, butterfly u, input r (1-based), table
 // column k = (b mod Ns).  All template arguments are compile-time so register tables stay in VGPRs.
 // Twiddles are scalar complex (Cx<S>) even when the data is two-lane (Cx<V>, S = ScalarOf<V>).
@@ -159,7 +170,8 @@ struct BlockFFT {
   // 256 KiB), so the exchange goes through ONE plane of real numbers twice -- real parts, then imaginary parts (the
   // two are independent registers): half the buffer for twice the barriers.
   static constexpr bool SPLIT =
-      SH_OVERRIDE < 0 && K > 1 && (long long)(N + (N >> r0_shift())) * (long long)sizeof(Cx<V>) > 160LL * 1024;
+      SH_OVERRIDE < 0 && K > 1 &&
+      (xm_force_split<PL>::value || (long long)(N + (N >> r0_shift())) * (long long)sizeof(Cx<V>) > 160LL * 1024);
   static constexpr int SH = SPLIT ? xm_pad_shift((int)sizeof(V)) : (SH_OVERRIDE >= 0 ? SH_OVERRIDE : r0_shift());
   // in units of Cx<V> (SPLIT: a plane of N padded V's)
   static constexpr int lds_elems() { return K > 1 ? (SPLIT ? (N + (N >> SH) + 1) / 2 : (N + (N >> SH))) : 0; }

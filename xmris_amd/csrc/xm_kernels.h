@@ -259,8 +259,14 @@ struct WorkQueue {
 // =================================================================================================
 // Generic fused kernel.  blockDim = NT * SPB, one spectrum per NT threads.
 // =================================================================================================
+// waves per SIMD to leave room for: a plan that asks for the plane-by-plane exchange does so to fit TWO workgroups
+template <class PL, int SPB>
+constexpr int pipe_waves() {
+  return xm_force_split<PL>::value ? (2 * PL::NT * SPB / 256 > 8 ? 8 : 2 * PL::NT * SPB / 256) : 1;
+}
+
 template <class T, class PL, int SPB>
-__global__ __launch_bounds__(PL::NT* SPB) void k_pipe(PipeArgs<T> A) {
+__global__ __launch_bounds__(PL::NT* SPB, (pipe_waves<PL, SPB>())) void k_pipe(PipeArgs<T> A) {
   constexpr int N = PL::N, NT = PL::NT, P = PL::P;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
   const int t = threadIdx.x % NT;
