@@ -389,6 +389,7 @@ def main():
     run_steps(2, False)  # first use: plans, tables, pinned buffers, worker threads
     gc.collect()
     gc.freeze()
+    prime_spent_ms = 0.0
     if args.prime_ms > 0:  # untimed: until the wall clock says the device has been busy for a while
         t_prime = time.perf_counter()
         best, last_batch = float("inf"), float("inf")
@@ -405,6 +406,7 @@ def main():
                 dist.broadcast(flag, src=0, group=host_group)
                 go = bool(flag.item())
             if not go:
+                prime_spent_ms = spent
                 break
             t_b = time.perf_counter()
             run_steps(8, False)
@@ -414,12 +416,18 @@ def main():
     if args.warmup:
         run_steps(args.warmup, False)
     barrier()
+    import resource
+
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     cpu0 = sum(os.times()[:2])
     t_start = time.perf_counter()
     timed_trace, timed_results = run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t_start
     cpu_cores = (sum(os.times()[:2]) - cpu0) / elapsed  # this process's threads, in cores, over the timed region
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_noise = {"major_faults": ru1.ru_majflt - ru0.ru_majflt, "minor_faults": ru1.ru_minflt - ru0.ru_minflt,
+                  "involuntary_switches": ru1.ru_nivcsw - ru0.ru_nivcsw}  # of this process, over the timed region
     read_times(timed_trace, timed_results)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if rccl_group is not None else "cpu")
@@ -430,6 +438,8 @@ def main():
         print("main_ms", [round(v, 3) for v in times["main_ms"]], file=sys.stderr)
         print("period_ms", [round(v, 3) for v in times["period_ms"]], file=sys.stderr)
         print("pre_ms", [round(v, 3) for v in times["pre_ms"]], file=sys.stderr)
+        for k in ("exchange_ms", "solve_ms", "gen_ms", "polish_ms", "table_ms"):
+            print(k, [round(v, 3) for v in times[k]], file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nv * args.steps / elapsed
     main_ms = float(np.mean(times["main_ms"]))
@@ -497,6 +507,8 @@ def main():
         "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0)}
                         if speculate else {"enabled": False}),
         "prime_ms": args.prime_ms,
+        "prime_ms_spent": round(prime_spent_ms, 1),
+        "host_noise_timed_region": host_noise,
         "host_cores_used_rank0": cpu_cores,
     }
     if world > 1:
@@ -507,7 +519,7 @@ def main():
         print(f"[rank {rank}] search_latency_exchange_to_use {np.mean(times['solve_ms']):.3f} ms (max {np.max(times['solve_ms']):.3f}), "
               f"device_period median {np.median(per) if per else float('nan'):.3f} ms, searches owned "
               f"{len(times['gen_ms'])}/{args.steps}, generations {np.mean(times['gen_ms']) if times['gen_ms'] else float('nan'):.3f} ms, "
-              f"team budget {aps.default_threads()} threads on {len(os.sched_getaffinity(0))} CPUs, this process used "
+              f"team budget {aps.stream_threads()} threads on {len(os.sched_getaffinity(0))} CPUs, this process used "
               f"{cpu_cores:.2f} cores, ms/step {ms_per_step:.3f}",
               file=sys.stderr)
     if not args.no_footnotes and world == 1:

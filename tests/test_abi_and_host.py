@@ -559,6 +559,12 @@ def test_solver_team_budget(monkeypatch):
     share = {"n": 16}
     monkeypatch.setattr(aps, "_cpu_share", lambda: share["n"])
     assert (aps.default_threads(), aps.burst_threads(), aps.scarce_cpus()) == (8, 16, False)
+    # a streaming call: three quarters of the share for two searches in flight (each busy half of its two device
+    # periods), half of it when the host paces the steps (every team spins all the time)
+    from xmris_amd import pipeline as pipe
+
+    assert (aps.stream_threads(), aps.stream_threads(host_paced=True)) == (12, 8)
+    assert (pipe._search_team(2), pipe._search_team(4)) == (6, 2)
     share["n"] = 6
     assert (aps.default_threads(), aps.burst_threads()) == (2, 4)
     share["n"] = 256
@@ -566,6 +572,7 @@ def test_solver_team_budget(monkeypatch):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     share["n"] = 16
     assert (aps.default_threads(), aps.burst_threads(), aps.scarce_cpus()) == (8, 8, True)
+    assert (aps.stream_threads(), pipe._search_team(2), pipe._search_team(4)) == (8, 4, 2)  # the node's budget, evenly
     share["n"] = 128
     assert (aps.default_threads(), aps.scarce_cpus()) == (16, False)
     share["n"] = 8

@@ -154,6 +154,25 @@ def burst_threads() -> int:
     return max(team, default_threads())
 
 
+def stream_threads(host_paced: bool = False) -> int:
+    """Thread budget of ALL the searches a streaming executor keeps in flight (`pipeline._search_workers` divides it).
+    One rank on its node, two searches in flight (the device paces the steps; each search is busy for about half of
+    the two device periods it has): THREE QUARTERS of the share, up to 12 -- six threads apiece run the generations in
+    1.25 instead of 1.45 ms at the same throughput (round 3, six interleaved pairs at the driver's K = 20: 51.5 vs
+    51.6 M spectra/s, 6.5 vs 5.3 cores busy), which leaves more slack for a slow or descheduled search (a first process
+    on a fresh box ran its searches 20 % slower and lost 13 % with four threads apiece).  The WHOLE share (eight
+    apiece, 1.05 ms) is 2 % faster when nothing goes wrong and stalled for 2-5 ms in three of seven runs: sixteen
+    spinning threads plus the launch thread oversubscribe a 16-CPU quota.  `host_paced` (more than two searches in
+    flight: every team spins all the time): half of the share -- with four teams of three BASELINE configs[1]
+    16,384 x 2048 -> 4096 lost 10 %.  Several ranks on one node, or XM_SOLVER_THREADS: `default_threads`."""
+    import os
+
+    if host_paced or os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
+        return default_threads()
+    cpus = min(16, _cpu_share())
+    return max(default_threads(), cpus - cpus // 4)
+
+
 class NativeObjective:
     """The three objectives evaluated by libxmris_hip.so's host solver (vectorised C++, fp64)."""
 

@@ -382,7 +382,7 @@ def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ov
     return results
 
 
-def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: int):
+def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: int | None = None):
     """(searches in flight, threads per search) for the streaming executor.  A search is O(1) per dataset on the host
     (measured, n_out = 8192, ACME: 3.2 / 1.9 / 1.1 / 0.76 ms of generations with 1 / 2 / 4 / 8 threads + 0.3 ms of
     polish; generations scale with n_out); the device period is the dataset's compulsory traffic at ~5.5 TB/s plus
@@ -393,9 +393,15 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
     lose to the interpreter lock (every search ends in scipy's polish, ~0.3 ms of Python)."""
     import os
 
+    def team_of(w):  # an explicit budget (tests, tuning) is divided evenly
+        return max(1, threads // w) if given else _search_team(w)
+
+    given = threads is not None
+    if not given:
+        threads = aps.stream_threads()
     if os.environ.get("XM_SEARCH_WORKERS"):  # tuning switch
         w = max(2, int(os.environ["XM_SEARCH_WORKERS"]))
-        return w, max(1, threads // w)
+        return w, team_of(w)
     device_ms = n_rows * (plan.n_in + plan.n_out) * elem_bytes / 5.5e9 + 0.12
     speedup = {1: 1.0, 2: 1.73, 4: 3.05, 8: 4.25, 16: 5.7}
     w = 2
@@ -403,7 +409,13 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
     gain = speedup[max(k for k in speedup if k <= team)]
     if (0.3 + 3.2 * (plan.n_out / 8192.0) / gain) / w > 0.8 * device_ms and threads >= 4:
         w = 4
-    return w, max(1, threads // w)
+    return w, team_of(w)
+
+
+def _search_team(workers: int) -> int:
+    """Threads per search with `workers` searches in flight (`autophase_solver.stream_threads`: more than two in flight
+    means the host paces the steps)."""
+    return max(1, aps.stream_threads(host_paced=workers > 2) // max(1, workers))
 
 
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
@@ -428,7 +440,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
     # searches running ahead of the main pass being queued (= worker threads): two where the device period is longer
     # than a search, more -- with smaller teams, which use the cores better -- where the host would pace the steps
-    workers, team = _search_workers(plan, nb, x0.element_size(), aps.default_threads())
+    workers, team = _search_workers(plan, nb, x0.element_size())
     if exchange is not None:
         # several ranks: the look-ahead fixes the ORDER of the exchange calls, which every rank must make alike --
         # it may not depend on anything a rank measures or owns (its shard size, its share of the host's cores).
@@ -517,7 +529,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "8")))
     # searches in flight at once share the host: each gets an equal part of the team
     n_workers = s_ahead if s_ahead >= 2 else 0
-    team = max(1, aps.default_threads() // max(1, n_workers))  # per search in flight
+    team = _search_team(n_workers) if n_workers else aps.stream_threads()  # per search in flight
     pool = None
     if n_workers:
         pool = plan.extra.get(("search_pool", n_workers))
@@ -543,7 +555,6 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                            refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
                            if use_guess else None)
 
-    full_team = aps.default_threads()
     # the pipeline-filling search (the first main pass waits for it) takes the whole CPU share for its millisecond:
     # four A/B pairs at the driver's K = 20: 53.1 -> 53.8 M spectra/s
     fill_team = aps.burst_threads()
