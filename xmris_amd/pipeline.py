@@ -450,7 +450,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     # (round 3: the selection stage of dataset j on a stream of its own beside the coarse spectra of dataset j + 1,
     # gated so that it never shares the chip with a main pass, hides nothing -- the coarse-spectra kernel fills the
-    # chip, 1.20 vs 1.20 ms per step; let loose beside the main kernel it costs 6 %.  Everything stays on one stream.)
+    # chip, 1.20 vs 1.20 ms per step; let loose beside the main kernel it costs 6 %.  Only the winner's fp64 spectrum
+    # (one workgroup, 18 us) on a high-priority stream beside the next main pass: that pass gets 15 us longer, -0.6 % at
+    # K = 20 and +0.4 % at K = 100 over six A/B pairs.  Everything stays on one stream.)
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     ring = g_ahead + 2
     distinct = list({id(x): x for x in inputs}.values())
