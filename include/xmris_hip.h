@@ -222,6 +222,10 @@ long xm_solver_nfev(void* solver);
 /* team size of one objective evaluation inside xm_solver_de (<= 0: min(16, hardware threads / 2); 1 = serial);
  * returns the value set.  Outside xm_solver_de evaluations are always serial. */
 int xm_solver_set_threads(void* solver, int threads);
+/* f(x) and its forward-difference gradient (n = 1 or 2 parameters in degrees, box [lb, ub]) exactly as scipy's L-BFGS-B
+ * requests them for the polish of phasing.py:276-284 (approx_derivative "2-point", abs_step 1e-8, bounds-aware steps);
+ * n + 1 evaluations in one batch.  Returns 0, or -1 for bad arguments. */
+int xm_solver_fg(void* solver, const double* x, int n, const double* lb, const double* ub, double* f_out, double* g_out);
 /* the differential-evolution generations (no polish); returns 0 = converged, 1 = maxiter reached */
 int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxiter, double* x_out /*[2]*/,
                  double* fun_out, int* nfev_out, int* nit_out);

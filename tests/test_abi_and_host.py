@@ -446,15 +446,22 @@ def test_deferred_chain_metadata_matches_materialised_data(monkeypatch):
     assert not xm.LabeledArray(x, ("v", "time"), {"time": t}).xmr.zero_fill(target_points=128).is_deferred
 
 
-def test_lean_polish_is_scipys_minimize_to_the_bit(oracle):
+@pytest.mark.parametrize("fg", ["native", "numpy"])
+def test_lean_polish_is_scipys_minimize_to_the_bit(oracle, monkeypatch, fg):
     """`autophase_solver.polish_lbfgsb` drives scipy's compiled L-BFGS-B core itself (no ScalarFunction / bounds
     front end) with a restated forward-difference gradient: x, fun, jac, nfev, nit, success must equal
     `scipy.optimize.minimize(..., method="L-BFGS-B", bounds=...)` -- the polish `differential_evolution` runs for the
     reference (phasing.py:276-284) -- bit for bit, for all three objectives, one and two parameters, starts inside,
-    ON the bounds (the difference step flips there) and next to them, converged at once or after tens of iterations."""
+    ON the bounds (the difference step flips there) and next to them, converged at once or after tens of iterations.
+    `fg`: the f-and-gradient requests answered by one native call (`xm_solver_fg`, the default) or spelled out in numpy."""
     import scipy.optimize
 
     from xmris_amd import autophase_solver as aps
+
+    if fg == "numpy":
+        monkeypatch.setenv("XM_POLISH_NUMPY_FG", "1")
+    else:
+        monkeypatch.delenv("XM_POLISH_NUMPY_FG", raising=False)
 
     rng = np.random.default_rng(3)
     n_iter = []

@@ -208,6 +208,19 @@ class NativeObjective:
         self._lib.xm_solver_score_batch(self._h, buf.ctypes.data, int(xs.shape[1]), int(xs.shape[0]), out.ctypes.data)
         return out
 
+    def fg(self, x, lb, ub):
+        """(f, forward-difference gradient) at x inside the box [lb, ub] in ONE native call (`xm_solver_fg`): what
+        `polish_lbfgsb` otherwise spells out in ~20 numpy operations per request, under the interpreter lock that the
+        other searches in flight and the launch thread are waiting for."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.empty(len(x))
+        f = np.empty(1)
+        rc = self._lib.xm_solver_fg(self._h, x.ctypes.data, len(x), lb.ctypes.data, ub.ctypes.data, f.ctypes.data,
+                                    g.ctypes.data)
+        if rc:
+            raise ValueError("xm_solver_fg rejected its arguments")
+        return float(f[0]), g
+
     def de(self, p0_only, seed=42, tol=0.01, maxiter=1000):
         import ctypes
 
@@ -236,6 +249,8 @@ def polish_lbfgsb(obj, x0, bounds, force_scipy: bool = False):
     x, fun, nfev, nit, success are scipy's to the bit (tests/test_abi_and_host.py).  The three points of one
     f-and-gradient request go to the native objective in ONE call.  Any surprise in scipy's private interface
     (this follows 1.15.3, the version SURVEY pins) -> the public `minimize`."""
+    import os
+
     import scipy
     import scipy.optimize
 
@@ -256,11 +271,17 @@ def polish_lbfgsb(obj, x0, bounds, force_scipy: bool = False):
     pgtol, abs_step = 1e-5, 1e-8
     x0 = np.clip(np.asarray(x0, dtype=np.float64).ravel(), lb, ub)
     state = {"nfev": 0, "x": None, "f": None, "g": None}
+    native_fg = hasattr(obj, "fg") and n <= 2 and not os.environ.get("XM_POLISH_NUMPY_FG")  # (switch: cross-checks)
 
     def func_and_grad(x):
         if state["x"] is not None and np.array_equal(x, state["x"]):
             return state["f"], state["g"]
         xc = np.array(x, dtype=np.float64)
+        if native_fg:  # the same arithmetic in one native call (bit-equal: tests/test_abi_and_host.py)
+            f, g = obj.fg(xc, lb, ub)
+            state["nfev"] += n + 1
+            state.update(x=xc, f=f, g=g)
+            return f, g
         # approx_derivative: absolute step, relative fallback when it vanishes, flipped where it leaves the bounds
         sign = (xc >= 0).astype(float) * 2 - 1
         h = np.full(n, abs_step)

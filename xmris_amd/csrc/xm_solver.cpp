@@ -277,4 +277,36 @@ int xm_solver_de(void* h, int p0_only, unsigned seed, double tol, int maxiter, d
   return status;
 }
 
+// f and its forward-difference gradient at x (n = 1 or 2 parameters), as scipy's L-BFGS-B front end requests them:
+// approx_derivative(method="2-point", abs_step=1e-8, bounds=(lb, ub)) -- absolute step, relative fallback where it
+// vanishes in x's precision, flipped where x + h leaves the bounds, one-sided towards the wider side where neither
+// direction fits -- with the step taken as the exactly representable (x + h) - x.  The n + 1 points go to the objective
+// in one batch.  This translation unit keeps IEEE semantics (no fast-math, no contraction): the values equal the numpy
+// statement of the same arithmetic (`autophase_solver.polish_lbfgsb`) bit for bit.
+int xm_solver_fg(void* h, const double* x, int n, const double* lb, const double* ub, double* f_out, double* g_out) {
+  if (!h || !x || !lb || !ub || !f_out || !g_out || n < 1 || n > 2) return -1;
+  double pts[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, dx[2] = {0.0, 0.0}, vals[3];
+  for (int r = 0; r <= n; ++r)
+    for (int i = 0; i < n; ++i) pts[r][i] = x[i];
+  for (int i = 0; i < n; ++i) {
+    const double xc = x[i];
+    double step = 1e-8;
+    volatile double moved = xc + step;  // (x + h) - x in double, never folded
+    if (moved - xc == 0.0) step = 1.4901161193847656e-08 * (xc >= 0.0 ? 1.0 : -1.0) * std::max(1.0, std::fabs(xc));
+    const double lower = xc - lb[i], upper = ub[i] - xc;
+    const double xt = xc + step;
+    const bool violated = xt < lb[i] || xt > ub[i];
+    const bool fitting = std::fabs(step) <= std::max(lower, upper);
+    if (violated && fitting) step = -step;
+    if (!fitting) step = upper >= lower ? upper : -lower;
+    volatile double p = xc + step;
+    pts[1 + i][i] = p;
+    dx[i] = p - xc;
+  }
+  xm_solver_score_batch(h, &pts[0][0], n, n + 1, vals);
+  *f_out = vals[0];
+  for (int i = 0; i < n; ++i) g_out[i] = (vals[1 + i] - vals[0]) / dx[i];
+  return 0;
+}
+
 }  // extern "C"
