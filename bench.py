@@ -418,6 +418,16 @@ def main():
     barrier()
     import resource
 
+    def cgroup_cpu_stat():
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+        except (OSError, ValueError):
+            return {}
+
+    from xmris_amd import _lib as _xl
+
+    backups0 = _xl.load().xm_solver_pool_backups()
+    cg0 = cgroup_cpu_stat()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     cpu0 = sum(os.times()[:2])
     t_start = time.perf_counter()
@@ -428,6 +438,11 @@ def main():
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_noise = {"major_faults": ru1.ru_majflt - ru0.ru_majflt, "minor_faults": ru1.ru_minflt - ru0.ru_minflt,
                   "involuntary_switches": ru1.ru_nivcsw - ru0.ru_nivcsw}  # of this process, over the timed region
+    host_noise["solver_shares_backed_up"] = _xl.load().xm_solver_pool_backups() - backups0  # xm_solver_obj.cpp, "Stragglers"
+    cg1 = cgroup_cpu_stat()
+    for k in ("nr_throttled", "throttled_usec", "nr_periods"):  # CPU-bandwidth throttling of the whole cgroup
+        if k in cg0 and k in cg1:
+            host_noise["cgroup_" + k] = cg1[k] - cg0[k]
     read_times(timed_trace, timed_results)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if rccl_group is not None else "cpu")
@@ -440,6 +455,12 @@ def main():
         print("pre_ms", [round(v, 3) for v in times["pre_ms"]], file=sys.stderr)
         for k in ("exchange_ms", "solve_ms", "gen_ms", "polish_ms", "table_ms"):
             print(k, [round(v, 3) for v in times[k]], file=sys.stderr)
+        if timed_trace and "t_search_begin" in timed_trace[-1]:  # where a late search lost its time
+            t0 = timed_trace[0]["t_start"]
+            for name, a, b in (("search_dispatch_ms", "t_exchanged", "t_search_begin"), ("search_run_ms", "t_search_begin", "t_search_end"),
+                               ("search_done_to_collect_ms", "t_search_end", "t_collect"), ("collect_to_solved_ms", "t_collect", "t_solved")):
+                print(name, [round((e[b] - e[a]) * 1e3, 3) if a in e and b in e else None for e in timed_trace], file=sys.stderr)
+            print("t_collect_ms", [round((e["t_collect"] - t0) * 1e3, 2) for e in timed_trace if "t_collect" in e], file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nv * args.steps / elapsed
     main_ms = float(np.mean(times["main_ms"]))

@@ -226,6 +226,9 @@ int xm_solver_set_threads(void* solver, int threads);
  * requests them for the polish of phasing.py:276-284 (approx_derivative "2-point", abs_step 1e-8, bounds-aware steps);
  * n + 1 evaluations in one batch.  Returns 0, or -1 for bad arguments. */
 int xm_solver_fg(void* solver, const double* x, int n, const double* lb, const double* ub, double* f_out, double* g_out);
+/* diagnostics: work shares that a search's own thread computed in place of a team member that was not there in time
+ * (still asleep, descheduled) -- the value of every evaluation is the same either way */
+long xm_solver_pool_backups(void);
 /* the differential-evolution generations (no polish); returns 0 = converged, 1 = maxiter reached */
 int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxiter, double* x_out /*[2]*/,
                  double* fun_out, int* nfev_out, int* nit_out);

@@ -493,6 +493,47 @@ def test_lean_polish_is_scipys_minimize_to_the_bit(oracle, monkeypatch, fg):
     assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev
 
 
+def test_solver_team_survives_a_member_that_is_not_there():
+    """A team member that is asleep or descheduled must not stall the search: the searching thread waits a grace
+    period, then computes the missing share itself (`xm_solver_obj.cpp`, "Stragglers").  With the test hook that
+    puts member 2 to sleep for 3 ms before every fifth job, a 4-thread search returns EXACTLY what the serial search
+    returns (every work unit has one value, whoever computes it), takes nowhere near the sum of the naps, and the
+    backup counter moves.  (Own process: the hook is read when the pool is created.)"""
+    import subprocess
+    import sys
+
+    code = r"""
+import time, json, numpy as np
+from xmris_amd import autophase_solver as aps, _lib
+rng = np.random.default_rng(5)
+n = 8192
+t = np.arange(n // 2) / 5000.0
+x = sum(a * np.exp(-d * t) * np.exp(2j * np.pi * f * t + 1j * p) for a, d, f, p in ((1.0, 20.0, 310.0, 0.7), (0.6, 35.0, -820.0, -1.1)))
+x = x + 0.02 * (rng.standard_normal(t.size) + 1j * rng.standard_normal(t.size))
+sl = np.fft.fftshift(np.fft.fft(np.pad(x, (0, n - t.size)), norm="ortho"))
+fr = np.fft.fftshift(np.fft.fftfreq(n, 1 / 5000.0))
+k = int(np.argmax(np.abs(sl)))
+out = {}
+for th in (1, 4):
+    t0 = time.perf_counter()
+    p0, p1, opt = aps.solve(sl, fr, float(fr[k]), k, 1, threads=th)
+    out[th] = (p0, p1, float(opt.fun), int(opt.nfev), int(opt.nit), time.perf_counter() - t0)
+print(json.dumps({"serial": out[1], "team": out[4], "backups": int(_lib.load().xm_solver_pool_backups())}))
+"""
+    env = dict(os.environ, XM_SOLVER_TEST_STALL="2,3000")
+    env.pop("XM_SOLVER_THREADS", None)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stderr[-2000:]
+    import json
+
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    assert got["serial"][:5] == got["team"][:5]  # p0, p1, fun, nfev, nit: bit for bit
+    assert got["backups"] >= 5
+    jobs = got["team"][3] / 4  # at least a quarter of the evaluations as hand-offs... each fifth one napped 3 ms
+    assert got["team"][5] < 0.25 * (jobs / 5) * 3e-3 + 0.5, got  # far below the sum of the naps
+
+
 def test_restated_xarray_semantics_one_by_one(monkeypatch):
     """The reference leans on four xarray behaviours that this package has to restate for its own container (and
     that `tests/_fake_xarray.py` cannot vouch for -- it only carries data in and out).  One assertion each, against

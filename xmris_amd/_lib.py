@@ -66,6 +66,7 @@ SIGNATURES = {
     "xm_solver_score": (ctypes.c_double, [_p, _p, _i]),
     "xm_solver_score_batch": (None, [_p, _p, _i, _i, _p]),
     "xm_solver_fg": (_i, [_p, _p, _i, _p, _p, _p, _p]),
+    "xm_solver_pool_backups": (ctypes.c_long, []),
     "xm_solver_nfev": (ctypes.c_long, [_p]),
     "xm_solver_set_threads": (_i, [_p, _i]),
     "xm_solver_de": (_i, [_p, _i, _u, ctypes.c_double, _i, _p, _p, _p, _p]),

@@ -5,10 +5,13 @@
 // evaluation lasts ~6 us on one core, far below what a fork/join runtime costs).  Compiled with
 // -O3 -ffast-math -mavx2 -mfma; the summation tree is fixed, so values do not depend on the team.  Host code only.
 #include <immintrin.h>
+#include <x86intrin.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -238,18 +241,42 @@ struct Solver {
 // publish their (p0, p1), bump a generation counter, every member takes its share of the work units
 // (evaluation x 2048-sample part), the caller combines the per-part sums serially in part order (so the
 // value is independent of the team size and of the batching).
+//
+// Stragglers.  A batch is ~10 us of work per member and a search runs ~150 of them, so a member that is not there --
+// still asleep when the search starts (a futex wake-up on a busy 256-CPU host was seen to take 3-8 ms, with no
+// involuntary context switch and no cgroup throttling on record) or descheduled in mid-search -- used to stall the
+// whole team for as long as it stayed away: isolated searches of 4-8 ms instead of 1.4, one in every few runs of 20
+// datasets, each a 3-9 ms hole between two main passes.  The caller therefore waits for a missing member only for a
+// grace period and then computes that member's share ITSELF into a backup buffer (the work units are deterministic:
+// whoever computes them gets the same five sums), a few microseconds instead of milliseconds.  What this needs:
+//   * jobs are immutable once published: a ring of descriptors (with their own copy of the parameters); a member
+//     copies the descriptor of the generation it saw and discards the copy when the caller has lapped the ring
+//     meanwhile (it may be torn);
+//   * a late member writes only its own slot and acknowledges only the generation it computed, so the caller never
+//     reads a slot that is being written;
+//   * the solver outlives every member that may touch it: a member raises `busy` before and checks the pool's phase
+//     after (Dekker), park() flips the phase first and then waits for the busy flags -- a member that wakes up after
+//     the search is over never starts on its job.
 struct Pool {
-  static constexpr int kMaxWorkers = 31, kMaxLocal = 128;
+  static constexpr int kMaxWorkers = 31, kMaxLocal = 128, kRing = 32, kMaxJobEvals = 128;
+  static constexpr uint64_t kGraceCycles = 80000, kSuspectGraceCycles = 6000;  // TSC ticks: ~30 us, ~2.5 us
   // One slot per team member: its acknowledgement AND its chunk partial sums share the same cache
   // lines, so the caller pays one coherence miss per worker (prefetched together), not one per flag
   // plus one per result line, and nobody does a contended read-modify-write.
   struct alignas(128) Slot {
     std::atomic<uint64_t> ack{0};
+    std::atomic<int> busy{0};
     double sums[5 * kMaxLocal];
+  };
+  struct Job {
+    const Solver* s = nullptr;
+    int nchunk = 0, neval = 1, team = 1;
+    double params[2 * kMaxJobEvals];  // (p0, p1) in radians per evaluation
   };
   std::vector<std::thread> th;
   alignas(128) std::atomic<uint64_t> gen{0};
-  alignas(128) std::atomic<int> state{0};  // 0 parked, 1 spinning, 2 exit
+  alignas(128) std::atomic<uint64_t> phase{0};  // even: parked, odd: a search is running (one value per search)
+  std::atomic<int> quit{0};
   std::atomic<int> spin_team{0};           // members (caller included) of the search that activated the pool: only
                                            // workers with id < spin_team wake up and spin -- a pool that once served a
                                            // 16-thread search must not spin 15 workers beside a 2-thread one (round 2
@@ -257,41 +284,64 @@ struct Pool {
   std::mutex mu;
   std::condition_variable cv;
   Slot slot[kMaxWorkers + 1];
-  // current job
-  const Solver* s = nullptr;
-  const double* params = nullptr;  // (p0, p1) in radians per evaluation of the job
-  int nchunk = 0, neval = 1, team = 1;
+  Job ring[kRing];
+  // caller's side of the current job
+  const Job* cur = nullptr;
+  bool backed_up[kMaxWorkers + 1] = {};
+  bool suspect[kMaxWorkers + 1] = {};  // missed a batch of this search: short grace until it is on time again
+  std::vector<double> backup = std::vector<double>((size_t)(kMaxWorkers + 1) * 5 * kMaxLocal);
+  std::atomic<long> backups{0};  // shares the caller computed for a missing member (diagnostics)
+
+  // test hook (XM_SOLVER_TEST_STALL="<member>,<microseconds>"): that member sleeps before every 5th job it takes
+  int stall_id = -1, stall_us = 0;
+  bool no_backup = false;  // tuning switch XM_SOLVER_NO_BACKUP: wait for every member however long it takes (round 2)
+  Pool() {
+    if (const char* e = std::getenv("XM_SOLVER_TEST_STALL")) std::sscanf(e, "%d,%d", &stall_id, &stall_us);
+    no_backup = std::getenv("XM_SOLVER_NO_BACKUP") != nullptr;
+  }
 
   bool in_use = false;  // guarded by g_pools_mu
   // task j = evaluation j / nchunk, part j % nchunk (nchunk = parts per evaluation); member id takes tasks
-  // id, id + team, ... -> slot[id].sums[local]
-  void run_share(int id) {
+  // id, id + team, ... -> sums[local]
+  static void run_share(const Job& jb, int id, double* sums) {
     int local = 0;
-    const int ntask = nchunk * neval;
-    for (int j = id; j < ntask; j += team, ++local) {
-      const int e = j / nchunk, c = j - e * nchunk;
-      s->acme_part(c, params[2 * e], params[2 * e + 1], slot[id].sums + 5 * local);
+    const int ntask = jb.nchunk * jb.neval;
+    for (int j = id; j < ntask; j += jb.team, ++local) {
+      const int e = j / jb.nchunk, c = j - e * jb.nchunk;
+      jb.s->acme_part(c, jb.params[2 * e], jb.params[2 * e + 1], sums + 5 * local);
     }
   }
   void worker(int id) {
     uint64_t seen = 0;
+    Job jb;
     for (;;) {
+      uint64_t ph;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return state.load() == 2 || (state.load() == 1 && id < spin_team.load()); });
-        if (state.load() == 2) return;
+        cv.wait(lk, [&] { return quit.load() || ((phase.load() & 1) && id < spin_team.load()); });
+        if (quit.load()) return;
+        ph = phase.load();
       }
-      while (state.load(std::memory_order_acquire) == 1) {
+      while (phase.load(std::memory_order_acquire) == ph) {
         const uint64_t g = gen.load(std::memory_order_acquire);
-        if (g != seen) {
-          seen = g;
-          if (id < team) {
-            run_share(id);
-            slot[id].ack.store(g, std::memory_order_release);
-          }
-        } else {
+        if (g == seen) {
           _mm_pause();
+          continue;
         }
+        seen = g;
+        const Job& src = ring[g % kRing];
+        if (id >= src.team) continue;  // (a torn read here only costs a pass of the loop)
+        jb = src;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (gen.load(std::memory_order_acquire) - g >= (uint64_t)(kRing - 1)) continue;  // lapped: the copy may be torn
+        if (id >= jb.team) continue;
+        slot[id].busy.store(1, std::memory_order_seq_cst);
+        if (phase.load(std::memory_order_seq_cst) == ph) {  // the search (and its solver) is still there
+          if (id == stall_id && g % 5 == 0) std::this_thread::sleep_for(std::chrono::microseconds(stall_us));
+          run_share(jb, id, slot[id].sums);
+          slot[id].ack.store(g, std::memory_order_release);
+        }
+        slot[id].busy.store(0, std::memory_order_release);
       }
     }
   }
@@ -308,28 +358,53 @@ struct Pool {
     {
       std::lock_guard<std::mutex> lk(mu);
       spin_team.store(team_size);
-      state.store(1);
+      for (int w = 0; w <= kMaxWorkers; ++w) suspect[w] = false;
+      phase.fetch_add(1, std::memory_order_seq_cst);  // -> odd
     }
     cv.notify_all();
   }
-  void park() { state.store(0, std::memory_order_release); }
-  bool active() const { return state.load(std::memory_order_acquire) == 1; }
+  void park() {
+    phase.fetch_add(1, std::memory_order_seq_cst);  // -> even: no member starts on a job from here on
+    for (size_t w = 1; w <= th.size(); ++w)
+      while (slot[w].busy.load(std::memory_order_seq_cst)) _mm_pause();  // a member in mid-share still reads the solver
+  }
+  bool active() const { return (phase.load(std::memory_order_acquire) & 1) != 0; }
   bool fits(int tasks, int t) const {
     return t - 1 <= (int)th.size() && t <= spin_team.load() && (tasks + t - 1) / t <= kMaxLocal;
   }
-  // partial sums of task j after eval(): slot[j % team].sums[5 * (j / team)]
-  const double* task_sums(int j) const { return slot[j % team].sums + 5 * (j / team); }
+  // partial sums of task j after eval(): member j % team, its local task j / team
+  const double* task_sums(int j) const {
+    const int w = j % cur->team;
+    return (backed_up[w] ? backup.data() + (size_t)w * 5 * kMaxLocal : slot[w].sums) + 5 * (j / cur->team);
+  }
   void eval(const Solver* sv, const double* p01r, int count, int chunks, int t) {
-    s = sv;
-    params = p01r;
-    neval = count;
-    nchunk = chunks;
-    team = t;
-    const uint64_t g = gen.fetch_add(1, std::memory_order_release) + 1;
-    run_share(0);
-    for (int w = 1; w < team; ++w) __builtin_prefetch(&slot[w], 0, 3);
-    for (int w = 1; w < team; ++w)
-      while (slot[w].ack.load(std::memory_order_acquire) != g) _mm_pause();
+    const uint64_t g = gen.load(std::memory_order_relaxed) + 1;
+    Job& jb = ring[g % kRing];
+    jb.s = sv;
+    jb.nchunk = chunks;
+    jb.neval = count;
+    jb.team = t;
+    std::memcpy(jb.params, p01r, sizeof(double) * 2 * (size_t)count);
+    cur = &jb;
+    gen.store(g, std::memory_order_release);
+    run_share(jb, 0, slot[0].sums);
+    backed_up[0] = false;
+    for (int w = 1; w < t; ++w) __builtin_prefetch(&slot[w], 0, 3);
+    const uint64_t t0 = __rdtsc();
+    for (int w = 1; w < t; ++w) {
+      backed_up[w] = false;
+      const uint64_t grace = suspect[w] ? kSuspectGraceCycles : kGraceCycles;
+      while (slot[w].ack.load(std::memory_order_acquire) != g) {
+        if (!no_backup && __rdtsc() - t0 > grace) {  // not there: its share is a few microseconds of the caller's time
+          run_share(jb, w, backup.data() + (size_t)w * 5 * kMaxLocal);
+          backed_up[w] = suspect[w] = true;
+          backups.fetch_add(1, std::memory_order_relaxed);
+          break;
+        }
+        _mm_pause();
+      }
+      if (!backed_up[w]) suspect[w] = false;  // there (again)
+    }
   }
 };
 
@@ -364,7 +439,7 @@ void Solver::acme_batch(const double* p01r, int count, double* out) const {
   }
   Pool& pool = *poolp;
   // as many evaluations per hand-off as the per-member result slots hold
-  const int per = std::max(1, (Pool::kMaxLocal * threads) / nchunk);
+  const int per = std::max(1, std::min(Pool::kMaxJobEvals, (Pool::kMaxLocal * threads) / nchunk));
   for (int e0 = 0; e0 < count; e0 += per) {
     const int g = std::min(per, count - e0);
     pool.eval(this, p01r + 2 * e0, g, nchunk, threads);
@@ -498,6 +573,16 @@ void xm_solver_pool_begin(int threads) {
   if (!p) return;
   p->ensure(threads - 1);
   p->activate(threads);
+}
+
+// shares of a batch that a search's own thread computed because the member they belong to was not there in time
+// (asleep, descheduled), over all pools since the library was loaded: diagnostics
+long xm_solver_pool_backups(void) {
+  long n = 0;
+  std::lock_guard<std::mutex> lk(g_pools_mu);
+  for (int i = 0; i < kPools; ++i)
+    if (g_pools[i]) n += g_pools[i]->backups.load(std::memory_order_relaxed);
+  return n;
 }
 
 void xm_solver_pool_end(void) {

@@ -276,7 +276,7 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
     spectral shape: always); correctness never does.
 
     `trace`, if given, receives one dict per dataset: host timestamps (`t_start`, `t_exchanged`, `t_solved`,
-    `t_table`) and torch events around the two kernels (`pre0`, `pre1`, `main0`, `main1`).
+    `t_table`; speculative schedule: also `t_search_begin`, `t_search_end` on the search's thread and `t_collect`) and torch events around the two kernels (`pre0`, `pre1`, `main0`, `main1`).
     Returns the list of AutophaseResult (p0, p1 filled on every rank; `.speculation` = "hit" / "repaired" with
     `speculate`)."""
     import time
@@ -561,8 +561,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # four A/B pairs at the driver's K = 20: 53.1 -> 53.8 M spectra/s
     fill_team = aps.burst_threads()
 
-    def search(sl, k, pivot, threads):
-        return aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads, polish=polish)
+    def search(sl, k, pivot, threads, ev):
+        ev["t_search_begin"] = time.perf_counter()  # (on the worker thread: dispatch latency = this - t_exchanged)
+        out = aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads, polish=polish)
+        ev["t_search_end"] = time.perf_counter()
+        return out
 
     pending = {}  # dataset -> (partial result, future or None)
 
@@ -583,7 +586,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
             # at a time and have two device periods each
             th = fill_team if j == 0 else team  # (smaller teams for the searches right behind the first: slower, -1...3 %)
-            fut = pool.submit(search, sl, int(k), res.pivot, th) if pool is not None else search(sl, int(k), res.pivot, th)
+            fut = (pool.submit(search, sl, int(k), res.pivot, th, ev) if pool is not None
+                   else search(sl, int(k), res.pivot, th, ev))
         pending[j] = (res, fut)
 
     def verify(i):
@@ -647,6 +651,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             guessed += 1
             guess(guessed)
         res, fut = pending.pop(i)
+        ev["t_collect"] = time.perf_counter()
         if fut is not None:
             p0, p1, opt = fut.result() if pool is not None else fut
             res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
