@@ -506,7 +506,7 @@ def main():
         "breakdown_ms": {
             ("guess_kernel_row_l1" if speculate else "prepass_kernel"): pre_ms, "main_kernel": main_ms,
             "selection_wait_and_exchange": float(np.mean(times["exchange_ms"])),
-            # speculative schedule: searches run two datasets ahead on worker threads -- this is the LATENCY from a
+            # speculative schedule: searches run three datasets ahead on worker threads -- this is the LATENCY from a
             # dataset's exchange to the moment its (p0, p1) is consumed, not host time on the critical path
             ("search_latency_exchange_to_use" if speculate else "slice_de_solve_broadcast"): float(np.mean(times["solve_ms"])),
             "solver_generations": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
@@ -520,7 +520,7 @@ def main():
         },
         "end_to_end_roofline_frac": value / world * (bytes_per * nt + bytes_per * N) / 1e9 / HBM_PEAK_GBPS,
         "autophase": {k: last.get(k) for k in ("p0", "p1", "pivot", "flat", "owner", "nfev")},
-        "schedule": (("guess kernels run 3 and (p0, p1) searches 2 datasets ahead of the main pass being queued (independent "
+        "schedule": (("guess kernels run 4 and (p0, p1) searches 3 datasets ahead of the main pass being queued (independent "
                       "datasets); the main pass returns the true global arg-max and every guess is verified (repaired if "
                       "wrong) before the next main pass" if speculate else
                       "pre-pass of step i+1 overlaps the host solve of step i (independent datasets)") if overlap

@@ -612,7 +612,7 @@ def test_solver_team_budget(monkeypatch):
     from xmris_amd import pipeline as pipe
 
     assert (aps.stream_threads(), aps.stream_threads(host_paced=True)) == (12, 8)
-    assert (pipe._search_team(2), pipe._search_team(4)) == (6, 2)
+    assert (pipe._search_team(2), pipe._search_team(3), pipe._search_team(4)) == (6, 4, 2)
     share["n"] = 6
     assert (aps.default_threads(), aps.burst_threads()) == (2, 4)
     share["n"] = 256
@@ -620,7 +620,7 @@ def test_solver_team_budget(monkeypatch):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     share["n"] = 16
     assert (aps.default_threads(), aps.burst_threads(), aps.scarce_cpus()) == (8, 8, True)
-    assert (aps.stream_threads(), pipe._search_team(2), pipe._search_team(4)) == (8, 4, 2)  # the node's budget, evenly
+    assert (aps.stream_threads(), pipe._search_team(2), pipe._search_team(3), pipe._search_team(4)) == (8, 4, 2, 2)  # the node's budget, evenly
     share["n"] = 128
     assert (aps.default_threads(), aps.scarce_cpus()) == (16, False)
     share["n"] = 8

@@ -156,15 +156,15 @@ def burst_threads() -> int:
 
 def stream_threads(host_paced: bool = False) -> int:
     """Thread budget of ALL the searches a streaming executor keeps in flight (`pipeline._search_workers` divides it).
-    One rank on its node, two searches in flight (the device paces the steps; each search is busy for about half of
-    the two device periods it has): THREE QUARTERS of the share, up to 12 -- six threads apiece run the generations in
-    1.25 instead of 1.45 ms at the same throughput (round 3, six interleaved pairs at the driver's K = 20: 51.5 vs
-    51.6 M spectra/s, 6.5 vs 5.3 cores busy), which leaves more slack for a slow or descheduled search (a first process
-    on a fresh box ran its searches 20 % slower and lost 13 % with four threads apiece).  The WHOLE share (eight
-    apiece, 1.05 ms) is 2 % faster when nothing goes wrong and stalled for 2-5 ms in three of seven runs: sixteen
-    spinning threads plus the launch thread oversubscribe a 16-CPU quota.  `host_paced` (more than two searches in
-    flight: every team spins all the time): half of the share -- with four teams of three BASELINE configs[1]
-    16,384 x 2048 -> 4096 lost 10 %.  Several ranks on one node, or XM_SOLVER_THREADS: `default_threads`."""
+    One rank on its node, two or three searches in flight (the device paces the steps; each search is busy for
+    about half of the device periods it has): THREE QUARTERS of the share, up to 12 -- with two in flight, six threads
+    apiece ran the generations in 1.25 instead of 1.45 ms at the same throughput (round 3, six interleaved pairs at the
+    driver's K = 20: 51.5 vs 51.6 M spectra/s, 6.5 vs 5.3 cores busy); the executor now keeps THREE in flight with four
+    threads each (`pipeline._search_workers`: the same throughput again, a third device period of slack for a search
+    that runs late).  The WHOLE share (two teams of eight, 1.05 ms) is 2 % faster when nothing goes wrong and stalled
+    for 2-5 ms in three of seven runs: sixteen spinning threads plus the launch thread oversubscribe a 16-CPU quota.
+    `host_paced` (more than three searches in flight: every team spins all the time): half of the share -- with four
+    teams of three BASELINE configs[1] 16,384 x 2048 -> 4096 lost 10 %.  Several ranks on one node, or XM_SOLVER_THREADS: `default_threads`."""
     import os
 
     if host_paced or os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:

@@ -386,9 +386,8 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
     """(searches in flight, threads per search) for the streaming executor.  A search is O(1) per dataset on the host
     (measured, n_out = 8192, ACME: 3.2 / 1.9 / 1.1 / 0.76 ms of generations with 1 / 2 / 4 / 8 threads + 0.3 ms of
     polish; generations scale with n_out); the device period is the dataset's compulsory traffic at ~5.5 TB/s plus
-    ~0.12 ms of small launches.  Two searches at a time with half the team each (fewest datasets in flight) where
-    that keeps up with the device; otherwise four with a quarter each (a smaller team spends fewer core-milliseconds
-    per search).  Measured (16-CPU share; ms per step with 2 / 4 / 8 in flight): 16,384 x 2048 -> 4096: 0.73 / 0.60 /
+    ~0.12 ms of small launches.  Three searches at a time with a third of the team each where that keeps up with the
+    device; otherwise four with a quarter each (a smaller team spends fewer core-milliseconds per search).  Measured (16-CPU share; ms per step with 2 / 4 / 8 in flight): 16,384 x 2048 -> 4096: 0.73 / 0.60 /
     0.79, 32,768 x 1536: 0.49 / 0.47 / 0.66, 65,536 x 4096 -> 8192: 1.17 / 1.19 / 1.23 -- eight single-thread searches
     lose to the interpreter lock (every search ends in scipy's polish, ~0.3 ms of Python)."""
     import os
@@ -404,7 +403,11 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
         return w, team_of(w)
     device_ms = n_rows * (plan.n_in + plan.n_out) * elem_bytes / 5.5e9 + 0.12
     speedup = {1: 1.0, 2: 1.73, 4: 3.05, 8: 4.25, 16: 5.7}
-    w = 2
+    # Round 3: THREE in flight where the device paces the steps (teams of four out of twelve threads): a search then
+    # has three device periods, ~2 ms of slack instead of ~1 for a search that runs late (a contended host), at the
+    # same throughput on a quiet one -- six A/B pairs at K = 20: 51.7 vs 51.4 M spectra/s, three at K = 100: 55.35 vs
+    # 55.20, 5.7 instead of 6.8 cores busy.
+    w = 3
     team = max(1, threads // w)
     gain = speedup[max(k for k in speedup if k <= team)]
     if (0.3 + 3.2 * (plan.n_out / 8192.0) / gain) / w > 0.8 * device_ms and threads >= 4:
@@ -413,9 +416,9 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
 
 
 def _search_team(workers: int) -> int:
-    """Threads per search with `workers` searches in flight (`autophase_solver.stream_threads`: more than two in flight
-    means the host paces the steps)."""
-    return max(1, aps.stream_threads(host_paced=workers > 2) // max(1, workers))
+    """Threads per search with `workers` searches in flight (`autophase_solver.stream_threads`: more than three in
+    flight means the host paces the steps)."""
+    return max(1, aps.stream_threads(host_paced=workers > 3) // max(1, workers))
 
 
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
