@@ -348,6 +348,8 @@ def main():
         for r in results:
             if speculate:
                 spec_stats[r.speculation] = spec_stats.get(r.speculation, 0) + (1 if record else 0)
+                if getattr(r, "hedged", False) and record:
+                    spec_stats["hedged"] = spec_stats.get("hedged", 0) + 1
         res = results[-1]
         last.update(p0=res.p0, p1=res.p1, pivot=res.pivot, flat=res.flat_index, owner=res.owner)
         for r in results:
@@ -525,7 +527,8 @@ def main():
                       "wrong) before the next main pass" if speculate else
                       "pre-pass of step i+1 overlaps the host solve of step i (independent datasets)") if overlap
                      else "strictly serial steps"),
-        "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0)}
+        "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0),
+                         "searches_started_twice": spec_stats.get("hedged", 0)}
                         if speculate else {"enabled": False}),
         "prime_ms": args.prime_ms,
         "prime_ms_spent": round(prime_spent_ms, 1),

@@ -384,6 +384,47 @@ def test_speculative_stream_of_many_small_datasets_with_misses(mods, dtype):
         assert float((outs[k] - refs[k]).abs().max()) <= tol * float(refs[k].abs().max()), k
 
 
+def test_a_search_that_runs_late_is_started_a_second_time(mods, monkeypatch):
+    """`run_stream(speculate=True)` hedges a search whose thread lost its CPU: with the test hook that puts the search
+    thread of dataset 9 to sleep for 40 ms, the launch thread has the same search started again once it is later than
+    twice the typical run time and takes whichever ends first -- the result is the classic schedule's to the bit
+    (the search is a pure function of the slice), only that dataset is flagged, and the call does not wait out the nap."""
+    import time
+
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 96, 1024, 2048
+    t = np.arange(nt) * 2e-4
+    sets = []
+    for k in range(14):
+        x, _ = _three_peak(nv, nt, 2e-4, seed=700 + k)
+        x[(7 * k + 3) % nv] *= 2.0
+        sets.append(dev.to_device(x.astype("complex64")))
+    plan = pipe.make_plan(sets[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=sets[0].dtype, device="cuda") for _ in sets]
+    refs = [torch.empty_like(o) for o in outs]
+    ref = pipe.run_stream(sets, refs, plan)
+    pipe.run_stream(sets, outs, plan, speculate=True)  # warm: pools, plans
+    monkeypatch.setenv("XM_TEST_SLOW_SEARCH", "9,40")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    hedged_s = time.perf_counter() - t0
+    assert [k for k, r in enumerate(got) if r.hedged] == [9]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert (a.flat_index, a.target_idx, a.pivot, a.p0, a.p1) == (b.flat_index, b.target_idx, b.pivot, b.p0, b.p1), k
+        assert float((outs[k] - refs[k]).abs().max()) <= 2.5e-7 * float(refs[k].abs().max()), k
+    monkeypatch.setenv("XMRIS_AMD_HEDGE", "0")
+    t0 = time.perf_counter()
+    plain = pipe.run_stream(sets, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    waited_s = time.perf_counter() - t0
+    assert not any(r.hedged for r in plain) and waited_s > 0.035  # without the hedge the nap is on the critical path
+    assert hedged_s < waited_s - 0.015
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_speculative_schedule_on_an_all_zero_dataset(mods, dtype):
     """np.argmax of an all-zero array is 0 (phasing.py:229): the speculative schedule must guess row 0, verify row 0

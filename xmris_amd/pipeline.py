@@ -89,6 +89,7 @@ class AutophaseResult:
     owner: int = 0      # rank that owns the winning spectrum (run_stream)
     mine: bool = True   # ... and whether that is this rank
     speculation: str = ""  # run_stream(speculate=True): "hit" or "repaired"
+    hedged: bool = False   # run_stream(speculate=True): the search ran late and was started a second time (see there)
 
 
 class Selection:
@@ -564,11 +565,46 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # four A/B pairs at the driver's K = 20: 53.1 -> 53.8 M spectra/s
     fill_team = aps.burst_threads()
 
-    def search(sl, k, pivot, threads, ev):
+    slow_hook = os.environ.get("XM_TEST_SLOW_SEARCH")  # test hook "<dataset>,<ms>": that dataset's search thread naps first
+    slow_j, slow_ms = (int(slow_hook.split(",")[0]), float(slow_hook.split(",")[1])) if slow_hook else (-1, 0.0)
+
+    def search(sl, k, pivot, threads, ev, j=-1):
         ev["t_search_begin"] = time.perf_counter()  # (on the worker thread: dispatch latency = this - t_exchanged)
+        if j == slow_j and j >= 0:
+            time.sleep(slow_ms * 1e-3)
         out = aps.solve(sl, plan.freq, pivot, k, iw, method=method, p0_only=p0_only, threads=threads, polish=polish)
         ev["t_search_end"] = time.perf_counter()
         return out
+
+    # Hedged searches.  A search is O(1) work on ONE Python thread plus its team; when that thread loses its CPU (or
+    # is dispatched late) on a contended host the search ends milliseconds late and the device waits (seen: 3-10 ms
+    # searches with next to no team shares taken over, `profiles/r03/box_spread.txt`).  The result is a pure function
+    # of the slice, so when the launch thread needs a result that is later than twice the typical run time it has the
+    # SAME search started again on a spare thread with the whole team and takes whichever of the two ends first.  At
+    # most one dataset in eight (a uniformly slow host gains nothing from doing everything twice).
+    hedging = os.environ.get("XMRIS_AMD_HEDGE", "1") != "0"
+    run_hist, last_hedge = [], [-100]
+
+    def collect(i, fut, args, ev):
+        from concurrent.futures import TimeoutError as FutureTimeout
+
+        recent = run_hist[-9:]
+        if not hedging or i == 0 or len(recent) < 3 or i - last_hedge[0] < 8:
+            return fut.result(), False
+        typical = sorted(recent)[len(recent) // 2]
+        wait = ev["t_exchanged"] + 2.0 * typical + 0.5e-3 - time.perf_counter()
+        try:
+            return fut.result(timeout=max(wait, 0.0)), False
+        except FutureTimeout:
+            from concurrent.futures import FIRST_COMPLETED, wait as wait_first
+
+            last_hedge[0] = i
+            hedge_pool = plan.extra.get("hedge_pool")
+            if hedge_pool is None:
+                hedge_pool = plan.extra["hedge_pool"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="xm-hedge")
+            again = hedge_pool.submit(search, *args, fill_team, {})
+            done, _ = wait_first([fut, again], return_when=FIRST_COMPLETED)
+            return (fut.result() if fut in done else again.result()), True
 
     pending = {}  # dataset -> (partial result, future or None)
 
@@ -589,9 +625,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
             # at a time and have two device periods each
             th = fill_team if j == 0 else team  # (smaller teams for the searches right behind the first: slower, -1...3 %)
-            fut = (pool.submit(search, sl, int(k), res.pivot, th, ev) if pool is not None
+            fut = (pool.submit(search, sl, int(k), res.pivot, th, ev, j) if pool is not None
                    else search(sl, int(k), res.pivot, th, ev))
-        pending[j] = (res, fut)
+        pending[j] = (res, fut, (sl, int(k), res.pivot))
 
     def verify(i):
         """True global arg-max row of dataset i (its main pass has been queued) against the guess; repair."""
@@ -653,10 +689,15 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         while guessed < min(n_sets - 1, i + g_ahead):
             guessed += 1
             guess(guessed)
-        res, fut = pending.pop(i)
+        res, fut, search_args = pending.pop(i)
         ev["t_collect"] = time.perf_counter()
         if fut is not None:
-            p0, p1, opt = fut.result() if pool is not None else fut
+            if pool is not None:
+                (p0, p1, opt), res.hedged = collect(i, fut, search_args, ev)
+                if "t_search_end" in ev and "t_search_begin" in ev:
+                    run_hist.append(ev["t_search_end"] - ev["t_search_begin"])
+            else:
+                p0, p1, opt = fut
             res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
             res.timing = {"generations_ms": 1e3 * opt.get("t_generations", 0.0), "polish_ms": 1e3 * opt.get("t_polish", 0.0)}
         if broadcast is not None:
