@@ -583,13 +583,16 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # SAME search started again on a spare thread with the whole team and takes whichever of the two ends first.  At
     # most one dataset in eight (a uniformly slow host gains nothing from doing everything twice).
     hedging = os.environ.get("XMRIS_AMD_HEDGE", "1") != "0"
-    run_hist, last_hedge = [], [-100]
+    # typical run times, kept with the plan from call to call: the pipeline-filling search of a call (whole team, the
+    # device idle behind it) has a history of its own
+    run_hist, fill_hist = plan.extra.setdefault("search_run_hist", []), plan.extra.setdefault("fill_run_hist", [])
+    last_hedge = [-100]
 
     def collect(i, fut, args, ev):
         from concurrent.futures import TimeoutError as FutureTimeout
 
-        recent = run_hist[-9:]
-        if not hedging or i == 0 or len(recent) < 3 or i - last_hedge[0] < 8:
+        recent = (fill_hist if i == 0 else run_hist)[-9:]
+        if not hedging or len(recent) < 3 or i - last_hedge[0] < 8:
             return fut.result(), False
         typical = sorted(recent)[len(recent) // 2]
         wait = ev["t_exchanged"] + 2.0 * typical + 0.5e-3 - time.perf_counter()
@@ -695,7 +698,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             if pool is not None:
                 (p0, p1, opt), res.hedged = collect(i, fut, search_args, ev)
                 if "t_search_end" in ev and "t_search_begin" in ev:
-                    run_hist.append(ev["t_search_end"] - ev["t_search_begin"])
+                    hist = fill_hist if i == 0 else run_hist
+                    hist.append(ev["t_search_end"] - ev["t_search_begin"])
+                    del hist[:-16]
             else:
                 p0, p1, opt = fut
             res.p0, res.p1, res.nfev, res.fun = p0, p1, int(opt.nfev), float(opt.fun)
