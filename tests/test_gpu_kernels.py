@@ -232,6 +232,48 @@ def test_fused_pipeline_matches_staged_oracle(dev, oracle, nb, n_in, n_out, pad_
     assert _relerr(main.out.cpu().numpy(), staged.cpu().numpy().astype(np.complex128)) < 4 * tol
 
 
+def test_randomised_parity_sweep(dev):
+    """Random (n_in, n_out, pad_left, batch) over every transform family -- in-LDS powers of two up to 16384 (complex128
+    16384: plane-by-plane exchange), 3*2^k / 5*2^k in both stage orders, chirp-z incl. the convolution lengths 3072 and
+    16384, four-step -- window + phase table + per-row arg-max in one launch against numpy in fp64
+    (`scripts/fuzz_parity.py` runs the same sweep with more cases and other seeds)."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    direct = [512, 768, 1024, 1280, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 16384, 384, 640, 256, 64]
+    for case in range(36):
+        fam = ["direct", "direct", "chirp", "chirp3072", "chirp16k", "long"][case % 6]
+        if fam == "direct":
+            n_out = int(rng.choice(direct))
+        elif fam == "chirp":
+            n_out = int(rng.integers(3, 4096)) | 1
+        elif fam == "chirp3072":
+            n_out = int(rng.integers(1025, 1536))
+        elif fam == "chirp16k":
+            n_out = int(rng.integers(4097, 8192)) | 1
+        else:
+            n_out = int(rng.choice([12288, 10240, 24576, 20000]))
+        n_in = int(rng.integers(2, n_out + 1)) if rng.random() < 0.7 else n_out
+        pad = int(rng.integers(0, n_out - n_in + 1)) if rng.random() < 0.4 else 0
+        nb = int(rng.integers(1, 40)) if n_out <= 8192 else int(rng.integers(1, 6))
+        t = (np.arange(n_out) - pad) * 2e-4
+        w = np.exp(-np.pi * 5.0 * np.abs(t))
+        ph = np.exp(1j * (0.3 + 1e-3 * np.arange(n_out)))
+        for dtype in ("complex64", "complex128"):
+            x = (rng.standard_normal((nb, n_in)) + 1j * rng.standard_normal((nb, n_in))).astype(dtype)
+            xp = np.zeros((nb, n_out), dtype=np.complex128)
+            xp[:, pad:pad + n_in] = x
+            spec = np.fft.fftshift(np.fft.fft(xp * w, axis=1, norm="ortho"), axes=1)
+            xd = dev.to_device(x)
+            rd = torch.float32 if dtype == "complex64" else torch.float64
+            got = dev.pipeline_fused(xd, n_out, pad, window=torch.from_numpy(w).to("cuda", rd),
+                                     phase_table=torch.from_numpy(ph).to("cuda", xd.dtype), want_argmax=True)
+            tag = (fam, dtype, nb, n_in, n_out, pad)
+            assert _relerr(got.out.cpu().numpy().astype(np.complex128), spec * ph) < (3e-6 if dtype == "complex64" else 1e-13), tag
+            if dtype == "complex128":
+                np.testing.assert_array_equal(got.argidx.cpu().numpy(), np.argmax(np.abs(spec), axis=1), err_msg=str(tag))
+
+
 def test_unsupported_length_raises(dev):
     from xmris_amd import _lib
 
