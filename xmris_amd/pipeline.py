@@ -540,7 +540,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     if n_workers:
         pool = plan.extra.get(("search_pool", n_workers))
         if pool is None:
-            pool = plan.extra[("search_pool", n_workers)] = ThreadPoolExecutor(max_workers=n_workers,
+            # (one thread more than searches in flight: a search that was hedged keeps its thread until it ends)
+            pool = plan.extra[("search_pool", n_workers)] = ThreadPoolExecutor(max_workers=n_workers + 1,
                                                                               thread_name_prefix="xm-search")
 
     def guess(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
