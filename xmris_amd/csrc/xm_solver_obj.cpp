@@ -411,8 +411,8 @@ struct Pool {
 // A few pools so that several searches (independent datasets, one Python thread each) can run at the same time, each
 // with its own team.  A search owns its pool from xm_solver_pool_begin to xm_solver_pool_end ON ITS OWN THREAD
 // (t_pool): evaluations issued by any other thread (a polish, score calls from Python) never touch a team.
-constexpr int kPools = 4;
-Pool* g_pools[kPools] = {nullptr, nullptr, nullptr, nullptr};  // intentionally leaked: workers may outlive static destruction
+constexpr int kPools = 6;  // up to four searches in flight + one that was hedged and still runs + its second start
+Pool* g_pools[kPools] = {};  // created on first use, intentionally leaked: workers may outlive static destruction
 std::mutex g_pools_mu;
 thread_local Pool* t_pool = nullptr;
 
