@@ -14,7 +14,7 @@
 #include <mutex>
 #include <tuple>
 
-#define XM_VERSION_NUM 300  // 0.3.0 (round 3: xm_guess_*, xm_pipeline_key_native, XM_KEY_BYTES 131072)
+#define XM_VERSION_NUM 301  // 0.3.1 (round 3: xm_guess_*, xm_pipeline_key_native, XM_KEY_BYTES 131072; xm_solver_fg, xm_solver_pool_backups)
 
 static thread_local std::string g_err;
 int xm_fail(int code, const std::string& msg) {
