@@ -427,9 +427,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair).
 
     Software pipeline over the datasets (with `overlap`): while the main pass of dataset i is queued, the guess
-    kernels + selection stages of datasets up to i+3 are already on the stream and the (p0, p1) searches of
-    datasets i+1 and i+2 run on worker threads (each search is one native call that releases the GIL and brings its
-    own small team, `xm_solver_de`), so a search has two device periods to finish instead of racing one.  Every
+    kernels + selection stages of datasets up to i+4 are already on the stream and the (p0, p1) searches of
+    datasets i+1 ... i+3 run on worker threads (each search is one native call that releases the GIL and brings its
+    own small team, `xm_solver_de`), so a search has three device periods to finish instead of racing one
+    (`_search_workers`: three in flight where the device paces the steps, four where the host does).  Every
     dataset still gets all of its own work; the collective-like calls (`exchange`, `broadcast`) are made by this
     thread in dataset order, identically on every rank."""
     import os
@@ -626,8 +627,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res.owner, res.mine = owner, mine
         fut = None
         if mine:
-            # the first search fills the pipeline (the first main pass waits for it): whole team; the others run two
-            # at a time and have two device periods each
+            # the first search fills the pipeline (the first main pass waits for it): whole team; the others run
+            # three (four) at a time and have as many device periods each
             th = fill_team if j == 0 else team  # (smaller teams for the searches right behind the first: slower, -1...3 %)
             fut = (pool.submit(search, sl, int(k), res.pivot, th, ev, j) if pool is not None
                    else search(sl, int(k), res.pivot, th, ev))
