@@ -239,6 +239,15 @@ int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxit
  * pinned staging buffer for xm_phase_apply / xm_pipeline_fused).  Returns 0, or -1 for bad arguments. */
 int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, double pivot, void* out, int as_float);
 
+/* ---- (e) multi-GPU: publication primitives of the one-node O(1) exchange (xmris_amd/sharding.py::ShmExchange; the
+ * global arg-max and the one (p0, p1) of phasing.py:229, 276-290 cross the ranks through a shared-memory page).  HOST
+ * pointers.  The payload of a slot is written with plain stores, its sequence word with a release store, and readers
+ * poll the sequence words with acquire loads. */
+int64_t xm_atomic_load_acquire_i64(const int64_t* p);
+void xm_atomic_store_release_i64(int64_t* p, int64_t value);
+/* 1 once all `count` words (`stride_words` apart) are >= value; 0 if not within `spin_us` microseconds of busy polling */
+int xm_atomic_wait_all_ge_i64(const int64_t* p, int stride_words, int count, int64_t value, int spin_us);
+
 #ifdef __cplusplus
 }
 #endif

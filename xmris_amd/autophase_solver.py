@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 METHODS = ("acme", "peak_minima", "positivity")
+MSG_METHOD = "Method must be 'acme', 'peak_minima', or 'positivity'"  # phasing.py:268 (kept in dims.py too)
 
 
 def phase_angles(coords: np.ndarray, p0: float, p1: float, pivot: float):
@@ -80,8 +81,19 @@ def index_width_of(coords: np.ndarray, peak_width: float) -> int:
     return max(1, int(round((peak_width / 2.0) / step)))
 
 
+_CPU_SHARE = None
+
+
 def _cpu_share() -> int:
-    """CPUs this process may use: scheduler affinity, capped by the cgroup v2 quota."""
+    """CPUs this process may use: scheduler affinity, capped by the cgroup v2 quota.  Read once per process (the
+    executor asks on every dataset: a sched_getaffinity call and a file read on the launch thread; advisor, round 3)."""
+    global _CPU_SHARE
+    if _CPU_SHARE is None:
+        _CPU_SHARE = _read_cpu_share()
+    return _CPU_SHARE
+
+
+def _read_cpu_share() -> int:
     import os
 
     try:
@@ -402,7 +414,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     sl = np.asarray(sl, dtype=np.complex128)
     coords = np.asarray(coords, dtype=np.float64)
     if method not in METHODS:
-        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
+        raise ValueError(MSG_METHOD)
     if engine == "native" and len(sl) >= 2:
         opt = _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads, polish)
         return float(opt.x[0]), (float(opt.x[1]) if not p0_only else 0.0), opt
@@ -413,7 +425,7 @@ def solve(sl: np.ndarray, coords: np.ndarray, pivot: float, target_idx: int, ind
     elif method == "positivity":
         fn, args = roi_positivity_score, (sl, coords, pivot, target_idx, index_width)
     else:
-        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
+        raise ValueError(MSG_METHOD)
     bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
     opt = scipy.optimize.differential_evolution(
         fn, bounds=bounds, args=args, strategy="best1bin", tol=0.01, seed=42, disp=disp

@@ -28,7 +28,15 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   if (rc) return rc;
   // one row (64 KiB in + 128 KiB out) per ticket
   A.queue_chunk = 1;
-  const long long blocks = A.n_batch < resident ? A.n_batch : resident;
+  long long blocks = A.n_batch < resident ? A.n_batch : resident;
+  if constexpr ((MODE & ZF2_GKEY) != 0) {
+    // the arg-max key holds one 16-byte (value, row) slot per WAVE from word XM_KEY_C128_WORD on: a device with more
+    // resident workgroups than the buffer has slots runs with fewer (the rows come from the queue either way) instead
+    // of writing past XM_KEY_BYTES (advisor, round 3)
+    constexpr long long slots = ((long long)XM_KEY_BYTES - 8ll * XM_KEY_C128_WORD) / 16, waves = PL::NT / XM_WAVE;
+    static_assert(slots >= waves, "arg-max key too small for one workgroup");
+    if (blocks * waves > slots) blocks = slots / waves;
+  }
   rc = xm_queue_slot(&A.queue);
   if (rc) return rc;
   hipLaunchKernelGGL((k_zf2d<PL, MODE>), dim3((unsigned)blocks), dim3(PL::NT), lds, st, A);

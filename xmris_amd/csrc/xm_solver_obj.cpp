@@ -271,6 +271,9 @@ struct Pool {
   struct Job {
     const Solver* s = nullptr;
     int nchunk = 0, neval = 1, team = 1;
+    uint64_t phase = 0;  // the pool phase (= the search) that published it: a member that wakes into the NEXT search
+                         // on this pool before that search's first job still finds this descriptor in the ring
+                         // (its `seen` lags `gen`), and its solver may be gone -- it must not run it (advisor, round 3)
     double params[2 * kMaxJobEvals];  // (p0, p1) in radians per evaluation
   };
   std::vector<std::thread> th;
@@ -334,7 +337,7 @@ struct Pool {
         jb = src;
         std::atomic_thread_fence(std::memory_order_acquire);
         if (gen.load(std::memory_order_acquire) - g >= (uint64_t)(kRing - 1)) continue;  // lapped: the copy may be torn
-        if (id >= jb.team) continue;
+        if (id >= jb.team || jb.phase != ph) continue;  // (a job of an earlier search on this pool: stale)
         slot[id].busy.store(1, std::memory_order_seq_cst);
         if (phase.load(std::memory_order_seq_cst) == ph) {  // the search (and its solver) is still there
           if (id == stall_id && g % 5 == 0) std::this_thread::sleep_for(std::chrono::microseconds(stall_us));
@@ -384,6 +387,7 @@ struct Pool {
     jb.nchunk = chunks;
     jb.neval = count;
     jb.team = t;
+    jb.phase = phase.load(std::memory_order_relaxed);  // (odd: this search; only this thread changes it while it runs)
     std::memcpy(jb.params, p01r, sizeof(double) * 2 * (size_t)count);
     cur = &jb;
     gen.store(g, std::memory_order_release);

@@ -14,7 +14,7 @@ from . import pipeline as pl
 from .config import ATTRS, COORDS, DIMS
 from .labeled import Coordinate, LabeledArray, as_labeled, like_input
 from .processing._common import device_data
-from .dims import _check_dims, term_attrs
+from .dims import MSG_METHOD, MSG_MODE, MSG_MODE_ALL, MSG_POSITION, _check_dims, term_attrs
 
 
 def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str = DIMS.time,
@@ -31,15 +31,13 @@ def spectral_pipeline(da, target_points: int = 1024, lb: float = 1.0, dim: str =
     src = as_labeled(da)
     _check_dims(src, dim, "zero_fill")
     if position not in ("end", "symmetric"):
-        raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
+        raise ValueError(MSG_POSITION)
     if mode == "all":
-        raise NotImplementedError(
-            "autophase(mode='all'), one phase pair per spectrum, is not available (nor is it in the reference)"
-        )
+        raise NotImplementedError(MSG_MODE_ALL)
     elif mode != "single":
-        raise ValueError("unknown autophase mode: 'single' expected ('all' is reserved)")
+        raise ValueError(MSG_MODE)
     if method not in ("acme", "peak_minima", "positivity"):
-        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
+        raise ValueError(MSG_METHOD)
     t = src.coords[dim].values  # apodize_exp needs the coordinate (KeyError otherwise)
     host = _host_rows(src, dim)
     if host is not None:

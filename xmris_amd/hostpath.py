@@ -27,6 +27,7 @@ from . import pipeline as pl
 
 _STAGE = {}   # (device index, bytes) -> [pinned uint8 tensors]
 _POOL = None  # worker threads of the pageable -> pinned copies
+_LOCK = __import__("threading").Lock()  # the staging buffers are shared: one `run_host` at a time per process
 
 
 def _pool():
@@ -44,11 +45,21 @@ def min_bytes() -> int:
 
 def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end", window_host=None, method="acme",
              peak_width=100, target_coord=None, p0_only=False, polish="numpy", chunk_bytes: int = 128 << 20,
-             device="cuda", timing: dict | None = None, promote: bool = False):
+             device="cuda", timing: dict | None = None, promote: bool = False, pinned_result: bool | None = None):
     """`pipeline.run` for ``x_host`` = [n_batch, n_time] complex64 / complex128 rows in host memory.  Returns
     (phased spectra as a host ndarray [n_batch, n_out], AutophaseResult, plan).  `timing` (optional dict) receives the
     wall-clock split.  `promote`: complex64 rows are uploaded as they are and widened to complex128 in HBM (numpy's
-    promotion in the staged chain, fid.py:136-139: the result is complex128)."""
+    promotion in the staged chain, fid.py:136-139: the result is complex128).  `pinned_result`: the result array is
+    page-locked host memory handed out as a numpy view (fastest: the download lands in it directly; default, and
+    `XMRIS_AMD_PINNED_RESULT=0` switches it off); False -- or a failed page-locked allocation -- downloads through two
+    pinned staging buffers into an ordinary (pageable) array.  Concurrent calls are serialised (shared staging)."""
+    with _LOCK:
+        return _run_host(x_host, t, target_points, lb, position, window_host, method, peak_width, target_coord, p0_only,
+                         polish, chunk_bytes, device, timing, promote, pinned_result)
+
+
+def _run_host(x_host, t, target_points, lb, position, window_host, method, peak_width, target_coord, p0_only, polish,
+              chunk_bytes, device, timing, promote, pinned_result):
     import time
 
     import torch
@@ -70,6 +81,10 @@ def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end
     chunks = [(lo, min(nb, lo + rows)) for lo in range(0, nb, rows)]
     compute = torch.cuda.current_stream(xd.device)
     copy_in = torch.cuda.Stream(device=xd.device)
+    # xd / x_up come from the caching allocator of the COMPUTE stream: a recycled block may still have kernels queued
+    # there (a just-freed intermediate of a preceding device op) -- the uploads must not overtake them (advisor, round 3)
+    copy_in.wait_stream(compute)
+    x_up.record_stream(copy_in)
     stage_key = (xd.device.index or 0, rows * row_bytes)
     stage = _STAGE.get(stage_key)
     if stage is None:
@@ -120,10 +135,24 @@ def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end
     t2 = time.perf_counter()
 
     # ---- main pass || download ----------------------------------------------------------------------
-    out_host = torch.empty((nb, n), dtype=tdt, pin_memory=True)  # (recycled by torch's caching host allocator)
+    if pinned_result is None:
+        pinned_result = os.environ.get("XMRIS_AMD_PINNED_RESULT", "1") != "0"
+    out_host = None
+    if pinned_result:
+        try:
+            out_host = torch.empty((nb, n), dtype=tdt, pin_memory=True)  # (recycled by torch's caching host allocator)
+        except RuntimeError:  # no page-locked memory of that size to be had: staged download below
+            out_host = None
+    out_np = out_host.numpy() if out_host is not None else np.empty((nb, n), dtype=np.complex64 if tdt == torch.complex64
+                                                                   else np.complex128)
+    bounce = None if out_host is not None else [torch.empty((rows, n), dtype=tdt, pin_memory=True) for _ in range(2)]
     copy_out = torch.cuda.Stream(device=xd.device)
+    copy_out.wait_stream(compute)  # (the ring below comes from the compute stream's allocator, as above)
     ring = [torch.empty((rows, n), dtype=tdt, device=xd.device) for _ in range(2)]
+    for r_ in ring:
+        r_.record_stream(copy_out)
     drained = [None, None]
+    copies = [None, None]  # staged download: the host memcpy of the chunk that used this bounce buffer last
     for i, (lo, hi) in enumerate(chunks):
         b = i % 2
         if drained[b] is not None:
@@ -131,15 +160,27 @@ def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end
         pl.main_pass(plan, xd[lo:hi], ring[b][:hi - lo], res.p0, res.p1, res.pivot)
         done = torch.cuda.Event()
         done.record(compute)
+        if copies[b] is not None:
+            copies[b].result()  # the bounce buffer is free again
         with torch.cuda.stream(copy_out):
             copy_out.wait_event(done)
-            out_host[lo:hi].copy_(ring[b][:hi - lo], non_blocking=True)
+            dst = out_host[lo:hi] if out_host is not None else bounce[b][:hi - lo]
+            dst.copy_(ring[b][:hi - lo], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_out)
         drained[b] = ev
+        if out_host is None:
+            def unload(ev=ev, b=b, lo=lo, hi=hi):
+                ev.synchronize()
+                np.copyto(out_np[lo:hi], bounce[b][:hi - lo].numpy())
+
+            copies[b] = pool.submit(unload)
     copy_out.synchronize()
+    for c in copies:
+        if c is not None:
+            c.result()
     t3 = time.perf_counter()
     if timing is not None:
         timing.update(upload_prepass_s=t1 - t0, search_s=t2 - t1, main_download_s=t3 - t2, total_s=t3 - t0, chunks=len(chunks),
-                      bytes=int(x_host.nbytes + out_host.numel() * out_host.element_size()))
-    return out_host.numpy(), res, plan
+                      bytes=int(x_host.nbytes + out_np.nbytes), pinned_result=out_host is not None)
+    return out_np, res, plan

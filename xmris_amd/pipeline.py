@@ -21,6 +21,7 @@ import numpy as np
 
 from . import autophase_solver as aps
 from . import device as dev
+from .dims import MSG_POSITION
 
 
 @dataclass
@@ -61,7 +62,7 @@ def make_plan(x2, t: np.ndarray, target_points: int, lb, position: str = "end", 
         elif position == "symmetric":
             pad_left = (n_out - n_in) // 2
         else:
-            raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
+            raise ValueError(MSG_POSITION)
         tt = zero_fill_coords(t, n_out, pad_left) if len(t) > 1 else t
     win = np.exp(-np.pi * lb * tt) if lb is not None else np.ones(n_out)
     if window_host is not None:
@@ -109,7 +110,7 @@ class Selection:
                 torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device))
 
     def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False, key=None, slot=None,
-                 refine=None):
+                 refine=None, blocking=None):
         import torch
 
         n = plan.n_out
@@ -139,7 +140,7 @@ class Selection:
             dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
             dev.gather_row_c128(x2, self.h_flat, n, out=x1)
         dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
-        self.event = torch.cuda.Event(blocking=aps.scarce_cpus())
+        self.event = torch.cuda.Event(blocking=aps.scarce_cpus() if blocking is None else blocking)
         self.event.record()
 
     def wait(self):
@@ -492,7 +493,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     if os.environ.get("XM_GUESS_BAND"):  # tuning switch
         band = float(os.environ["XM_GUESS_BAND"])
     l1_keys = use_keys and not c128 and not use_guess  # round 2's guess stage leaves its winner in a key (complex64)
-    key = ("spec_bufs", nb, str(rd), ring, use_guess)
+    # (use_keys / l1_keys depend on the alignment of every input: buffers cached for one combination hold None where
+    # another needs arrays -- advisor, round 3)
+    key = ("spec_bufs", nb, str(rd), ring, use_guess, use_keys, l1_keys)
     bufs = plan.extra.get(key)
     if bufs is None:
         sel_rd = torch.float32 if use_guess else rd
@@ -561,7 +564,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
                            key=bufs["gkey"][b] if l1_keys else None, slot=bufs["sel_slots"][b],
                            refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
-                           if use_guess else None)
+                           if use_guess else None, blocking=blocking)
 
     # the pipeline-filling search (the first main pass waits for it) takes the whole CPU share for its millisecond:
     # four A/B pairs at the driver's K = 20: 53.1 -> 53.8 M spectra/s

@@ -12,7 +12,7 @@ import numpy as np
 
 from .. import device as dev
 from ..config import ATTRS, COORDS, DIMS
-from ..dims import _check_dims, term_attrs
+from ..dims import MSG_POSITION, _check_dims, term_attrs
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, deferred, device_data, like_input,
                       maybe_real, promote_for_float64_operand, promoted_dtype)
 from .fourier import fft, fftshift, ifft, ifftshift
@@ -96,7 +96,7 @@ def zero_fill(da, dim: str = DIMS.time, target_points: int = 1024, position: str
     elif position == "symmetric":
         pad_left = pad // 2
     else:
-        raise ValueError("zero_fill position: 'end' or 'symmetric' expected")
+        raise ValueError(MSG_POSITION)
     def compute():
         x, was_real = device_data(src)
         return maybe_real(dev.zero_fill(x, src.get_axis_num(dim), int(target_points), pad_left), was_real)

@@ -16,7 +16,7 @@ import numpy as np
 from .. import autophase_solver as aps
 from .. import device as dev
 from ..config import ATTRS, DIMS
-from ..dims import _check_dims
+from ..dims import MSG_METHOD, MSG_MODE, MSG_MODE_ALL, _check_dims, msg_phase_units
 from ._common import (Coordinate, LabeledArray, as_labeled, binary_op_name, device_data, like_input,
                       promote_for_float64_operand, to_host)
 
@@ -37,10 +37,7 @@ def _phase_labeled(src: LabeledArray, x, dim, p0, p1, pivot) -> LabeledArray:
     if pivot is not None and ATTRS.phase_pivot_coord in out.attrs:  # phasing.py:79-88
         old = out.attrs[ATTRS.phase_pivot_coord]
         if old != dim:
-            warnings.warn(  # (the reference warns here too; own wording)
-                f"phase along '{dim}' on data whose earlier phase steps were taken along '{old}': "
-                f"the pivot ({pivot}) is read in the units of '{dim}'"
-            )
+            warnings.warn(msg_phase_units(dim, old, pivot))  # phasing.py:84-88
     out.attrs[ATTRS.phase_p0] = p0  # phasing.py:91-94
     out.attrs[ATTRS.phase_p1] = p1
     out.attrs[ATTRS.phase_pivot] = pivot
@@ -147,13 +144,11 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
     _check_dims(src, dim, "autophase")
     kwargs.setdefault("disp", False)
     if mode == "all":
-        raise NotImplementedError(
-            "autophase(mode='all'), one phase pair per spectrum, is not available (nor is it in the reference)"
-        )
+        raise NotImplementedError(MSG_MODE_ALL)
     elif mode != "single":
-        raise ValueError("unknown autophase mode: 'single' expected ('all' is reserved)")
+        raise ValueError(MSG_MODE)
     if method not in aps.METHODS:
-        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
+        raise ValueError(MSG_METHOD)
     fused = _fused_chain(src, dim, method, peak_width, target_coord, p0_only, lb)
     if fused is not None:
         return like_input(fused, da)
@@ -184,7 +179,7 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
         work, work_coords = tmp.values, tmp.coords[dim].values
 
     if method not in aps.METHODS:
-        raise ValueError("unknown autophase method: choose 'acme', 'peak_minima' or 'positivity'")
+        raise ValueError(MSG_METHOD)
     import os
 
     # one accessor call, one search: the final polish runs on the numpy objective like the reference's (pipeline.run)

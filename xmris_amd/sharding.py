@@ -72,8 +72,10 @@ class ShmExchange:
     sequence numbers (a streaming caller runs the gathers of later datasets before the broadcast of an earlier
     one) and pick their bank by that number.  A rank can run at most one gather ahead of the slowest one (it needs
     everyone's entry to finish the next gather), and callers put at least one gather between two broadcasts, so
-    two banks would do; four leave slack.  x86 stores are observed in program order: payload first, then the
-    sequence number that publishes it."""
+    two banks would do; four leave slack.  Publication order: the payload words are written with plain stores, the
+    sequence word that publishes them with a RELEASE store and every poll reads it with ACQUIRE loads -- both in
+    the host library (`xm_atomic_store_release_i64`, `xm_atomic_wait_all_ge_i64`), so the protocol leans neither on
+    x86's store ordering nor on what the interpreter does between two numpy stores."""
 
     SLOT = 8   # int64 words per slot = one 64-byte cache line
     BANKS = 4
@@ -95,6 +97,11 @@ class ShmExchange:
         self._f = self._i.view(np.float64)
         self._seq = 0   # gathers done
         self._bseq = 0  # broadcasts done
+        self.calls = {"gather": 0, "broadcast": 0}  # per-rank call counts (tests compare them across the ranks)
+        from . import _lib
+
+        self._lib = _lib.load()
+        self._base = self._i.ctypes.data
 
     @staticmethod
     def nbytes(world: int) -> int:
@@ -143,17 +150,21 @@ class ShmExchange:
             raise OSError("ShmExchange: the ranks do not share a writable /dev/shm")
         return cls(buf, rank, world, timeout_s)
 
-    def _spin(self, cond):
-        """Poll until cond(): a short busy phase (ranks usually arrive together), then sleeping polls -- a
-        rank that waits a millisecond for the owner's search must not take a core away from the search."""
+    def _addr(self, bank: int, slot: int, word: int = 0) -> int:
+        return self._base + 8 * ((bank * (self.world + 1) + slot) * self.SLOT + word)
+
+    def _wait(self, addr: int, count: int, value: int):
+        """Until `count` sequence words (one per slot from `addr`) are >= value: a short busy phase in the library
+        (ranks usually arrive together; acquire loads), then sleeping polls -- a rank that waits a millisecond for the
+        owner's search must not take a core away from the search."""
         import time
 
-        for _ in range(200):
-            if cond():
-                return
+        wait = self._lib.xm_atomic_wait_all_ge_i64
+        if wait(addr, self.SLOT, count, value, 30) == 1:
+            return
         t_end = time.monotonic() + self.timeout_s
         nap = 2e-5  # backs off to 0.15 ms: what is waited for here is a search of a millisecond or more
-        while not cond():
+        while wait(addr, self.SLOT, count, value, 0) != 1:
             time.sleep(nap)
             nap = min(1.5e-4, nap * 1.5)
             if time.monotonic() > t_end:
@@ -164,11 +175,11 @@ class ShmExchange:
         self._seq += 1
         s, bank = self._seq, self._seq % self.BANKS
         slots_i, slots_f = self._i[bank], self._f[bank]
+        self.calls["gather"] += 1
         slots_f[self.rank, 1] = float(max_abs)
         slots_i[self.rank, 2] = int(global_flat)
-        slots_i[self.rank, 0] = s  # publish
-        seqs = slots_i[: self.world, 0]
-        self._spin(lambda: bool((seqs >= s).all()))
+        self._lib.xm_atomic_store_release_i64(self._addr(bank, self.rank), s)  # publish
+        self._wait(self._addr(bank, 0), self.world, s)
         return pick_winner([(float(slots_f[r, 1]), int(slots_i[r, 2])) for r in range(self.world)])
 
     def broadcast_params(self, values, owner: int):
@@ -176,6 +187,7 @@ class ShmExchange:
         self._bseq += 1
         s, bank = self._bseq, self._bseq % self.BANKS
         bi, bf = self._i[bank, self.world], self._f[bank, self.world]
+        self.calls["broadcast"] += 1
         if self.rank == owner:
             vals = [float(v) for v in values]
             if len(vals) > self.SLOT - 2:
@@ -183,7 +195,7 @@ class ShmExchange:
             for j, v in enumerate(vals):
                 bf[2 + j] = v
             bi[1] = len(vals)
-            bi[0] = s  # publish
+            self._lib.xm_atomic_store_release_i64(self._addr(bank, self.world), s)  # publish
             return vals
-        self._spin(lambda: bi[0] >= s)
+        self._wait(self._addr(bank, self.world), 1, s)
         return [float(bf[2 + j]) for j in range(int(bi[1]))]
