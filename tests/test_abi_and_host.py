@@ -369,24 +369,27 @@ def test_xarray_bridge_through_a_test_double(oracle, monkeypatch):
 
 
 def test_native_search_vs_scipy_divergence_sweep():
-    """How often does the native search (native generations + scipy polish on the native objective, -ffast-math) end
-    somewhere else than the reference's route (scipy.optimize.differential_evolution on the numpy objective,
-    phasing.py:276-284)?  60 seeded spectra of 3-5 Lorentzian lines with a random (p0, p1) distortion and noise,
-    three scores.
+    """How often does the native search end somewhere else than the reference's route
+    (scipy.optimize.differential_evolution on the numpy objective, phasing.py:276-284)?  60 seeded spectra of 3-5
+    Lorentzian lines with a random (p0, p1) distortion and noise, three scores.
 
-    The generations are the same search evaluation for evaluation (equal nfev up to the polish); where scipy's final
-    L-BFGS-B polish does not improve the best member -- the usual case -- the results are IDENTICAL, and every ACME
-    case of that kind must agree to 1e-4 degrees here.  An accepted polish walks a finite-difference gradient
-    (steps of 1e-8) over objectives that differ in their last bits between numpy and the native code, so its end
-    point moves by up to a few 1e-3 degrees; it, and the two piecewise ROI scores (min over a window / sums over
-    sign sets: plateaus and kinks, where "the same parameters" is not defined), are held to SURVEY section 7.3
-    contract (iii): an objective no worse than scipy's, to 1e-7 relative."""
+    The generations are the same search evaluation for evaluation (equal nfev).  scipy's final L-BFGS-B polish
+    usually does nothing -- the projected gradient at the best member is below pgtol, nit = 0, the member is kept --
+    and the default polish="exact" makes that test natively and hands every search that does NOT pass it to the
+    reference's own route (scipy's minimiser on the numpy objective).  So, accepted polishes included:
+      * ACME: (p0, p1) within 1e-4 degrees of the reference's route in EVERY case (round 3, native polish: up to
+        8e-4 / 4e-3 degrees where a polish iterated), identical wherever no polish ran;
+      * the two piecewise ROI scores (min over a window / sums over sign sets: plateaus and kinks -- whole regions
+        score exactly 0, ties between members decide the generations, "the same parameters" is not defined) are held
+        to SURVEY section 7.3 contract (iii): an objective no worse than scipy's, to 1e-7 relative.
+    polish="native" (what round 3's streaming executor ran) is measured beside it and only held to contract (iii)."""
     from xmris_amd import autophase_solver as aps
 
     n, sw = 2048, 5000.0
     t = np.arange(n) / sw
     freq = np.roll(np.fft.fftfreq(n, d=1 / sw), n // 2)
-    stats = {m: dict(n=0, identical=0, polished=0, dp0=0.0, dp1=0.0, dfun=0.0) for m in aps.METHODS}
+    stats = {m: dict(n=0, identical=0, polished=0, route_numpy=0, dp0=0.0, dp1=0.0, dfun=0.0, native_dp0=0.0, native_dp1=0.0)
+             for m in aps.METHODS}
     for seed in range(60):
         rng = np.random.default_rng(1000 + seed)
         k = int(rng.integers(3, 6))
@@ -400,21 +403,24 @@ def test_native_search_vs_scipy_divergence_sweep():
         spec = spec * np.exp(1j * aps.phase_angles(freq, rng.uniform(-150, 150), rng.uniform(-600, 600), pivot))
         iw = aps.index_width_of(freq, 100)
         method = aps.METHODS[seed % 3]
-        p0n, p1n, on = aps.solve(spec, freq, pivot, kmax, iw, method=method, engine="native")
+        p0n, p1n, on = aps.solve(spec, freq, pivot, kmax, iw, method=method, engine="native")  # polish="exact"
         p0s, p1s, os_ = aps.solve(spec, freq, pivot, kmax, iw, method=method, engine="scipy")
+        p0v, p1v, ov = aps.solve(spec, freq, pivot, kmax, iw, method=method, engine="native", polish="native")
         st = stats[method]
         dp0, dp1 = abs(p0n - p0s), abs(p1n - p1s)
-        dfun = (on.fun - os_.fun) / max(abs(os_.fun), 1e-300)
+        floor = 1e-12 * float(np.abs(spec).max())  # (the ROI scores are in data units and can be exactly 0)
+        dfun = (on.fun - os_.fun) / max(abs(os_.fun), floor * 1e7)
         st["n"] += 1
         st["identical"] += int(dp0 == 0.0 and dp1 == 0.0)
         st["polished"] += int(bool(on.get("polished")))
+        st["route_numpy"] += int(on.get("polish_route") == "numpy")
         st["dp0"], st["dp1"], st["dfun"] = max(st["dp0"], dp0), max(st["dp1"], dp1), max(st["dfun"], dfun)
-        if method == "acme" and not on.get("polished"):
-            assert dp0 < 1e-4 and dp1 < 1e-4 and on.nfev == os_.nfev, (seed, p0n, p0s, p1n, p1s, on.nfev, os_.nfev)
-        else:
-            assert dfun <= 1e-7, (seed, method, on.fun, os_.fun)
-            if method == "acme":
-                assert dp0 < 2e-2 and dp1 < 2e-2, (seed, dp0, dp1)
+        st["native_dp0"], st["native_dp1"] = max(st["native_dp0"], abs(p0v - p0s)), max(st["native_dp1"], abs(p1v - p1s))
+        if method == "acme":
+            assert on.nfev == os_.nfev, (seed, method, on.nfev, os_.nfev)
+            assert dp0 < 1e-4 and dp1 < 1e-4, (seed, method, p0n, p0s, p1n, p1s, on.get("polish_route"))
+        assert dfun <= 1e-7, (seed, method, on.fun, os_.fun)
+        assert (ov.fun - os_.fun) / max(abs(os_.fun), floor * 1e7) <= 1e-7, (seed, method, ov.fun, os_.fun)
     print("native vs scipy route per method:", stats)
     assert stats["acme"]["identical"] >= stats["acme"]["n"] - stats["acme"]["polished"]
 

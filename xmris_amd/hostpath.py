@@ -44,7 +44,7 @@ def min_bytes() -> int:
 
 
 def run_host(x_host: np.ndarray, t, target_points: int, lb, position: str = "end", window_host=None, method="acme",
-             peak_width=100, target_coord=None, p0_only=False, polish="numpy", chunk_bytes: int = 128 << 20,
+             peak_width=100, target_coord=None, p0_only=False, polish="exact", chunk_bytes: int = 128 << 20,
              device="cuda", timing: dict | None = None, promote: bool = False, pinned_result: bool | None = None):
     """`pipeline.run` for ``x_host`` = [n_batch, n_time] complex64 / complex128 rows in host memory.  Returns
     (phased spectra as a host ndarray [n_batch, n_out], AutophaseResult, plan).  `timing` (optional dict) receives the

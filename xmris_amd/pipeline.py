@@ -154,7 +154,7 @@ class Selection:
 
 def select_and_solve(x2, plan: PipelinePlan, absmax2, argidx, method="acme", peak_width=100, target_coord=None,
                      p0_only=False, exchange=None, rank_offset_rows=0, disp=False, on_host_phase=None,
-                     selection: "Selection | None" = None, threads=None, polish="native"):
+                     selection: "Selection | None" = None, threads=None, polish="exact"):
     """phasing.py:226-287 on the outputs of the pre-pass.  `exchange(max_abs, flat)` may merge the
     per-rank winners (returns (owner_is_me, global_flat)); default = single device.
     `on_host_phase()` is called once the device has nothing left to do for this dataset until the
@@ -209,16 +209,18 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
     """Fused hot path on ``x2`` = [n_batch, n_time] complex rows resident in HBM.
 
     Returns (phased [n_batch, n_out] tensor, AutophaseResult, plan).  `params=(p0, p1)` skips the
-    solver (used by parity tests that inject the oracle's parameters).  `polish`: "numpy" (default for this
-    one-dataset call, `XMRIS_AMD_POLISH` overrides) drives the search's final L-BFGS-B step with the numpy objective
-    like the reference does -- (p0, p1) then equal the reference's route to the last bit also on flat landscapes --
-    "native" keeps it in the library (what `run_stream` does: ~0.1 ms instead of ~5-10 ms)."""
+    solver (used by parity tests that inject the oracle's parameters).  `polish` (`XMRIS_AMD_POLISH` overrides the
+    default): "exact" -- the projected-gradient test that scipy's polish starts (and usually ends) with is made
+    natively, a search that does not pass it is polished on the reference's own route, scipy's minimiser on the numpy
+    objective: (p0, p1) equal the reference's to the last bit also on flat landscapes; "numpy" -- always that route
+    (~5-10 ms); "native" -- scipy's L-BFGS-B core on the native objective (~0.1 ms; its end point differs from the
+    reference's by ~1e-3 degrees when the polish iterates).  `run_stream` has the same default."""
     import os
 
     import torch
 
     if polish is None:
-        polish = os.environ.get("XMRIS_AMD_POLISH", "numpy")
+        polish = os.environ.get("XMRIS_AMD_POLISH", "exact")
 
     if plan is None:
         plan = make_plan(x2, t, target_points, lb)
@@ -253,7 +255,7 @@ def run(x2, t, target_points: int, lb: float, method: str = "acme", peak_width=1
 
 def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=None, rank_offset_rows: int = 0,
                overlap: bool = True, method: str = "acme", peak_width=100, target_coord=None, p0_only: bool = False,
-               trace: list | None = None, speculate: bool = False, polish: str = "native"):
+               trace: list | None = None, speculate: bool = False, polish: str | None = None):
     """The fused hot path over a SEQUENCE of independent datasets of one shape, software-pipelined.
 
     ``inputs[i]`` ([n_batch, n_in] complex rows in HBM) is transformed into ``outputs[i]`` ([n_batch, n_out]);
@@ -286,6 +288,10 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
     import torch
 
     n_sets = len(inputs)
+    if polish is None:
+        import os
+
+        polish = os.environ.get("XMRIS_AMD_POLISH", "exact")
     if n_sets != len(outputs):
         raise ValueError("inputs and outputs must have the same length")
     if n_sets == 0:
@@ -306,7 +312,7 @@ def run_stream(inputs, outputs, plan: PipelinePlan, *, exchange=None, broadcast=
 
 
 def _run_stream(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width,
-                target_coord, p0_only, trace, speculate, polish="native"):
+                target_coord, p0_only, trace, speculate, polish="exact"):
     import time
 
     import torch
@@ -424,7 +430,7 @@ def _search_team(workers: int) -> int:
 
 
 def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method,
-                            peak_width, p0_only, trace, polish="native"):
+                            peak_width, p0_only, trace, polish="exact"):
     """`run_stream(speculate=True)`: guess pass -> search -> main pass with true maxima -> verify (-> repair).
 
     Software pipeline over the datasets (with `overlap`): while the main pass of dataset i is queued, the guess

@@ -182,8 +182,8 @@ def autophase(da, dim: str = DIMS.frequency, method: str = "acme", mode: str = "
         raise ValueError(MSG_METHOD)
     import os
 
-    # one accessor call, one search: the final polish runs on the numpy objective like the reference's (pipeline.run)
+    # the search's final polish follows the reference's route wherever it does anything (pipeline.run, polish="exact")
     p0_opt, p1_opt, _ = aps.solve(work, work_coords, pivot, target_idx, index_width, method=method,
                                   p0_only=p0_only, disp=kwargs.get("disp"), threads=aps.burst_threads(),
-                                  polish=os.environ.get("XMRIS_AMD_POLISH", "numpy"))
+                                  polish=os.environ.get("XMRIS_AMD_POLISH", "exact"))
     return like_input(_phase_labeled(src, x, dim, p0_opt, p1_opt, pivot), da)  # phasing.py:290
