@@ -239,6 +239,42 @@ int xm_solver_de(void* solver, int p0_only, unsigned seed, double tol, int maxit
  * pinned staging buffer for xm_phase_apply / xm_pipeline_fused).  Returns 0, or -1 for bad arguments. */
 int xm_phase_table(const double* coords, int n, double p0_deg, double p1_deg, double pivot, void* out, int as_float);
 
+/* ---- A7 on the device: the (p0, p1) search of processing/phasing.py:276-284 for the ACME objective (:100-122) as ONE
+ * workgroup beside the streaming kernels (csrc/xm_search.hip): scipy 1.15.3's differential evolution for the
+ * reference's configuration (seed -> numpy RandomState stream, latin hypercube, best1bin, dither U[0.5, 1), CR 0.7,
+ * immediate updating, tol on std/mean) -- the trial vectors are scipy's bit for bit given equal comparisons of the
+ * energies -- followed by the test scipy's L-BFGS-B polish starts with (f and its forward-difference gradient at the
+ * best member; projected gradient against pgtol = 1e-5).  `slice`: the n complex128 bins of the spectrum through the
+ * global maximum, device-accessible (the selection stage leaves it in pinned host memory); its coordinate axis must
+ * be uniform, c[k] = c0 + k cstep, x_range = max c - min c > 0 (phasing.py:56-59).  The pivot is the coordinate of the
+ * first arg-max of |slice| (phasing.py:229-238).  `out` (device-accessible, e.g. pinned host memory) is filled when
+ * the search ends, `seq` last (system-scope release): poll it with xm_atomic_load_acquire_i64.  Asynchronous on
+ * `stream`; the stream's device must be current.  n <= 16576. */
+typedef struct {
+  double x[2];          /* p0, p1 in degrees (p1 = 0 with p0_only)                                                  */
+  double fun;           /* objective at x                                                                            */
+  double pg_norm;       /* L-BFGS-B's projected-gradient norm at x (forward differences, approx_derivative's steps) */
+  int32_t nfev, nit;    /* evaluations and generations of the differential evolution (the gradient test's n + 1
+                           evaluations are not counted)                                                              */
+  int32_t status;       /* 0 = converged, 1 = maxiter reached                                                        */
+  int32_t needs_polish; /* 0: pg_norm <= pgtol / 2, scipy's polish would return x unchanged; 1: the caller polishes
+                           (xmris_amd/autophase_solver.py, the reference's route)                                    */
+  int32_t target_idx;   /* first arg-max of |slice| (index of the pivot coordinate)                                  */
+  int32_t pad_;
+  uint64_t seq;         /* the launch's `seq`, written last                                                          */
+  double t_us[8];       /* diagnostics, microseconds as the optimiser's wave saw them: [0] naming the points,
+                           [1] phase tables, [2] drawing the next trial's random part (overlaps the workers' sums),
+                           [3] waiting for the sums, [4] taking the scores, [5] the whole search                     */
+} xm_search_result;
+int xm_search_supported(int n, int method, double x_range);
+int xm_search_launch(const void* slice, int n, double c0, double cstep, double x_range, int method, int p0_only,
+                     unsigned seed, double tol, int maxiter, uint64_t seq, xm_search_result* out, void* stream);
+/* The device objective alone (tests; cross-checks against the numpy statement): fs[e] = ACME score at
+ * (xs[2e], xs[2e+1]) degrees, e < count, pivot = coordinate of bin `target_idx` (< 0: the first arg-max of |slice|).
+ * `xs` / `fs` device-accessible. */
+int xm_search_eval(const void* slice, int n, double c0, double cstep, double x_range, int target_idx, int p0_only,
+                   const double* xs, int count, double* fs, void* stream);
+
 /* ---- (e) multi-GPU: publication primitives of the one-node O(1) exchange (xmris_amd/sharding.py::ShmExchange; the
  * global arg-max and the one (p0, p1) of phasing.py:229, 276-290 cross the ranks through a shared-memory page).  HOST
  * pointers.  The payload of a slot is written with plain stores, its sequence word with a release store, and readers

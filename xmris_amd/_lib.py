@@ -70,6 +70,10 @@ SIGNATURES = {
     "xm_solver_nfev": (ctypes.c_long, [_p]),
     "xm_solver_set_threads": (_i, [_p, _i]),
     "xm_solver_de": (_i, [_p, _i, _u, ctypes.c_double, _i, _p, _p, _p, _p]),
+    "xm_search_supported": (_i, [_i, _i, ctypes.c_double]),
+    "xm_search_launch": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _i, _u, ctypes.c_double, _i,
+                              ctypes.c_uint64, _p, _p]),
+    "xm_search_eval": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _i, _p, _i, _p, _p]),
     "xm_atomic_load_acquire_i64": (_l, [_p]),
     "xm_atomic_store_release_i64": (None, [_p, _l]),
     "xm_atomic_wait_all_ge_i64": (_i, [_p, _i, _i, _l, _i]),

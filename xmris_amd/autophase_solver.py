@@ -362,6 +362,27 @@ def _numpy_objective(sl, coords, pivot, target_idx, index_width, method):
     return lambda x: roi_positivity_score(x, sl, coords, pivot, target_idx, index_width)
 
 
+def polish_reference(sl, coords, pivot, target_idx, index_width, method, p0_only, x):
+    """The polish of `differential_evolution` on the reference's own route (phasing.py:276-284 with scipy's defaults):
+    scipy's L-BFGS-B minimiser on the NUMPY objective from the generations' best member `x`; accepted when it lowers
+    that objective.  Returns (x, fun, nfev, polished).  Used by every engine whose generations ended with a member
+    that does not pass scipy's projected-gradient test (`polish="exact"`; the device search's `needs_polish`)."""
+    import scipy.optimize
+
+    bounds = [(-180.0, 180.0)] if p0_only else [(-180.0, 180.0), (-4000.0, 4000.0)]
+    x = np.asarray(x, dtype=np.float64)[:len(bounds)]
+    fn = _numpy_objective(np.asarray(sl, dtype=np.complex128), np.asarray(coords, dtype=np.float64), pivot, target_idx,
+                          index_width, method)
+    fun = float(fn(x))
+    res = scipy.optimize.minimize(fn, np.copy(x), method="L-BFGS-B", bounds=bounds)
+    lo = np.array([b_[0] for b_ in bounds])
+    hi = np.array([b_[1] for b_ in bounds])
+    polished = bool(res.fun < fun and res.success and np.all(res.x <= hi) and np.all(lo <= res.x))
+    if polished:
+        return np.asarray(res.x, dtype=np.float64), float(res.fun), int(res.nfev), True
+    return x, fun, int(res.nfev), False
+
+
 def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None, polish="exact"):
     """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
     run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective

@@ -523,3 +523,71 @@ def fft_supported(n: int, complex128: bool = False) -> bool:
     if n == 1:
         return True
     return bool(_lib.load().xm_fft_supported(int(n), _lib.XM_C128 if complex128 else _lib.XM_C64))
+
+
+# ---------------------------------------------------------------------------------------------
+# A7 on the device: the (p0, p1) search as one workgroup beside the streaming kernels (csrc/xm_search.hip)
+# ---------------------------------------------------------------------------------------------
+SEARCH_RECORD_WORDS = 16  # xm_search_result: 128 bytes
+
+
+def search_supported(n: int, method: str = "acme", x_range: float = 1.0) -> bool:
+    """True when `search_launch` takes this slice length / objective (ACME, n <= 16576, a non-degenerate axis)."""
+    from .autophase_solver import METHODS
+
+    return method in METHODS and bool(_lib.load().xm_search_supported(int(n), METHODS.index(method), float(x_range)))
+
+
+def new_search_record():
+    """Pinned host record (`xm_search_result`) that a search kernel fills when it ends, `seq` (word 7) last."""
+    return _torch().zeros(SEARCH_RECORD_WORDS, dtype=_torch().int64, pin_memory=True)
+
+
+def uniform_axis(coords):
+    """(c0, cstep, x_range) of a coordinate axis when it is uniform to a few ulp (the fftfreq axis of this path), else
+    None: phasing.py:56-69's (c - pivot) / (max c - min c) is then linear in the bin index."""
+    c = np.asarray(coords, dtype=np.float64)
+    if c.size < 2:
+        return None
+    step = (c[-1] - c[0]) / (c.size - 1)
+    rng = float(c.max() - c.min())
+    if step == 0 or rng <= 0 or not np.all(np.abs(c - (c[0] + step * np.arange(c.size))) <= 4e-15 * rng):
+        return None
+    return float(c[0]), float(step), rng
+
+
+def search_launch(slice_c128, axis, record, seq: int, p0_only: bool = False, seed: int = 42, tol: float = 0.01,
+                  maxiter: int = 1000, stream=None):
+    """`xm_search_launch`: phasing.py:276-284's differential evolution for the ACME objective on `slice_c128` (n
+    complex128 bins, device-accessible: device memory or pinned host memory), asynchronous on `stream` (a
+    torch.cuda.Stream; default: the current one).  `axis` = `uniform_axis(coords)`.  `record` (`new_search_record`)
+    receives the result; `search_done(record, seq)` tells when."""
+    torch = _torch()
+    n = slice_c128.numel()
+    st = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+    _lib.call("xm_search_launch", slice_c128.data_ptr(), int(n), float(axis[0]), float(axis[1]), float(axis[2]), 0,
+              int(bool(p0_only)), int(seed), float(tol), int(maxiter), int(seq), record.data_ptr(), st)
+
+
+def search_done(record, seq: int) -> bool:
+    return int(_lib.load().xm_atomic_load_acquire_i64(record.data_ptr() + 56)) == int(seq)
+
+
+def read_search_record(record) -> dict:
+    """The fields of a finished `xm_search_result`."""
+    f = record.view(_torch().float64)
+    i = record.view(_torch().int32)
+    return dict(x=(float(f[0]), float(f[1])), fun=float(f[2]), pg_norm=float(f[3]), nfev=int(i[8]), nit=int(i[9]),
+                status=int(i[10]), needs_polish=bool(int(i[11])), target_idx=int(i[12]),
+                t_us=[float(v) for v in f[8:14]])
+
+
+def search_eval(slice_c128, axis, xs, target_idx: int = -1, p0_only: bool = False):
+    """`xm_search_eval`: the device objective at the rows of `xs` ([count, 2] degrees); synchronous (tests)."""
+    torch = _torch()
+    xs_t = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float64)).reshape(-1, 2).to(slice_c128.device if slice_c128.is_cuda else "cuda")
+    fs = torch.empty(xs_t.shape[0], dtype=torch.float64, device=xs_t.device)
+    _lib.call("xm_search_eval", slice_c128.data_ptr(), int(slice_c128.numel()), float(axis[0]), float(axis[1]),
+              float(axis[2]), int(target_idx), int(bool(p0_only)), xs_t.data_ptr(), int(xs_t.shape[0]), fs.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return fs.cpu().numpy()

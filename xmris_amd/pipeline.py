@@ -453,12 +453,37 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # searches running ahead of the main pass being queued (= worker threads): two where the device period is longer
     # than a search, more -- with smaller teams, which use the cores better -- where the host would pace the steps
     workers, team = _search_workers(plan, nb, x0.element_size())
+    # ---- search engine ------------------------------------------------------------------------------------------
+    # "device" (default where it applies): the search of a dataset runs as ONE workgroup on a side stream right behind
+    # the dataset's selection stage (`xm_search_launch`, csrc/xm_search.hip: scipy's generations bit for bit, then the
+    # projected-gradient test scipy's polish starts with) -- no host core computes anything, no team spins, and what a
+    # shared host does to its threads no longer reaches the device's schedule; a search that does not pass the test is
+    # polished by this thread on the reference's route.  A search takes milliseconds on its one CU, so the guess stages
+    # run `dev_ahead` datasets in front, and the first datasets of a call (the pipeline is still filling: nothing hides
+    # a search there) are searched by the host engine as before.  "host": round 3's worker threads + native teams.
+    axis = plan.extra.get("uniform_axis")
+    if axis is None:
+        axis = plan.extra["uniform_axis"] = dev.uniform_axis(plan.freq) or False
+    use_dev = (os.environ.get("XMRIS_AMD_SEARCH", "device") == "device" and polish == "exact" and method == "acme"
+               and overlap and axis is not False and dev.search_supported(n, method, axis[2]))
+    dev_ahead = 0
+    if use_dev:
+        # ~600 objective evaluations; measured per evaluation: 2.3 us + 0.4 us per 1000 bins (profiles/r04/device_search.txt)
+        est_ms = 600 * (2.3 + 0.4 * n / 1000.0) * 1e-3
+        device_ms = nb * (plan.n_in + plan.n_out) * x0.element_size() / 5.5e9 + 0.12
+        dev_ahead = int(min(24, max(3, -(-est_ms // device_ms) + 2)))
+        if os.environ.get("XM_SEARCH_AHEAD"):  # tuning switch
+            dev_ahead = max(1, int(os.environ["XM_SEARCH_AHEAD"]))
     if exchange is not None:
         # several ranks: the look-ahead fixes the ORDER of the exchange calls, which every rank must make alike --
         # it may not depend on anything a rank measures or owns (its shard size, its share of the host's cores).
         # Rank 0's choice goes to everyone (one more broadcast at the start of the call); without a broadcast
         # callable: two.
-        workers = int(round(broadcast([float(workers)], 0)[0])) if broadcast is not None else 2
+        if broadcast is not None:
+            got = broadcast([float(workers), float(dev_ahead if use_dev else 0)], 0)
+            workers, use_dev, dev_ahead = int(round(got[0])), use_dev and got[1] > 0, int(round(got[1]))
+        else:
+            workers, use_dev, dev_ahead = 2, False, 0
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     # (round 3: the selection stage of dataset j on a stream of its own beside the coarse spectra of dataset j + 1,
     # gated so that it never shares the chip with a main pass, hides nothing -- the coarse-spectra kernel fills the
@@ -466,6 +491,12 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # (one workgroup, 18 us) on a high-priority stream beside the next main pass: that pass gets 15 us longer, -0.6 % at
     # K = 20 and +0.4 % at K = 100 over six A/B pairs.  Everything stays on one stream.)
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
+    # device engine: the first `cpu_fill` datasets of the call are searched by the host engine (s_ahead at a time);
+    # from then on a dataset's search is a kernel that starts `dev_ahead` datasets before its main pass
+    cpu_fill = min(n_sets, s_ahead + 1) if use_dev else n_sets
+    use_dev = use_dev and cpu_fill < n_sets
+    if use_dev:
+        g_ahead = max(g_ahead, min(dev_ahead, n_sets - 1))
     ring = g_ahead + 2
     distinct = list({id(x): x for x in inputs}.values())
 
@@ -571,6 +602,70 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                            key=bufs["gkey"][b] if l1_keys else None, slot=bufs["sel_slots"][b],
                            refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
                            if use_guess else None, blocking=blocking)
+        if use_dev and exchange is None and j >= cpu_fill:
+            # one rank: the winner needs no exchange -- the search kernel is queued at once, gated on the selection
+            # stage by an event; this thread does not wait for either
+            dev_seq[j] = launch_dev_search(j, after=sel[b].event)
+
+    # ---- searches on the device (`use_dev`) ------------------------------------------------------------------------
+    dsearch, dev_seq = None, {}
+    if use_dev:
+        dsearch = plan.extra.get(("dev_search", ring))
+        if dsearch is None:
+            dsearch = plan.extra[("dev_search", ring)] = dict(
+                recs=[dev.new_search_record() for _ in range(ring)],
+                streams=[torch.cuda.Stream(device=x0.device) for _ in range(min(ring, 16))], seq=[0], retired=[])
+
+    def launch_dev_search(j, after=None):
+        """`xm_search_launch` for dataset j on a side stream; returns the sequence number its record will carry."""
+        b = j % ring
+        st = dsearch["streams"][j % len(dsearch["streams"])]
+        if after is not None:
+            st.wait_event(after)
+        dsearch["seq"][0] += 1
+        seq = dsearch["seq"][0]
+        dev.search_launch(sel[b].h_slice[0], axis, dsearch["recs"][b], seq, p0_only=p0_only, stream=st)
+        events[j]["t_search_begin"] = time.perf_counter()
+        return seq
+
+    def collect_dev(i, seq, ev):
+        """Result of dataset i's search kernel -> (p0, p1, k, nfev, fun, timing, hedged).  A search that does not pass
+        scipy's projected-gradient test is polished here on the reference's route; one that runs far beyond the usual
+        time (a landscape that keeps the generations going for tens of thousands of evaluations) is overtaken by the
+        host engine -- the search is a pure function of the slice."""
+        b = i % ring
+        rec = dsearch["recs"][b]
+        deadline = time.perf_counter() + max(4.0 * est_ms * 1e-3, 8e-3)
+        nap = 0.0
+        while not dev.search_done(rec, seq):
+            if time.perf_counter() > deadline:
+                sl = sel[b].h_slice[0].numpy().copy()
+                k = int(np.argmax(np.abs(sl)))
+                p0, p1, opt = search(sl, k, float(plan.freq[k]), fill_team, {})
+                # the kernel is still running: its record and its stream are retired (it will write the record when it
+                # ends; the stream's later searches would queue behind it)
+                dsearch["retired"].append((rec, dsearch["streams"][i % len(dsearch["streams"])]))
+                dsearch["recs"][b] = dev.new_search_record()
+                dsearch["streams"][i % len(dsearch["streams"])] = torch.cuda.Stream(device=x0.device)
+                return p0, p1, k, int(opt.nfev), float(opt.fun), {"generations_ms": 1e3 * opt.get("t_generations", 0.0),
+                                                                 "polish_ms": 1e3 * opt.get("t_polish", 0.0)}, True
+            if blocking:  # few cores per rank: do not spin beside another rank's launch thread
+                nap = min(1e-4, nap + 1e-5)
+                time.sleep(nap)
+        ev["t_search_end"] = time.perf_counter()
+        r = dev.read_search_record(rec)
+        k = r["target_idx"]
+        p0, p1 = r["x"]
+        nfev, fun = r["nfev"] + (1 if p0_only else 2) + 1, r["fun"]  # (+ the gradient test's evaluations, like scipy's count)
+        timing = {"generations_ms": 1e-3 * r["t_us"][5], "polish_ms": 0.0, "device": True}
+        if r["needs_polish"]:
+            t0 = time.perf_counter()
+            sl = sel[b].h_slice[0].numpy().copy()
+            x, fun, nfev_p, _ = aps.polish_reference(sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+            p0, p1 = float(x[0]), (float(x[1]) if not p0_only else 0.0)
+            nfev = r["nfev"] + nfev_p
+            timing["polish_ms"] = 1e3 * (time.perf_counter() - t0)
+        return p0, (p1 if not p0_only else 0.0), k, nfev, fun, timing, False
 
     # the pipeline-filling search (the first main pass waits for it) takes the whole CPU share for its millisecond:
     # four A/B pairs at the driver's K = 20: 53.1 -> 53.8 M spectra/s
@@ -603,8 +698,15 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         from concurrent.futures import TimeoutError as FutureTimeout
 
         recent = (fill_hist if i == 0 else run_hist)[-9:]
-        if not hedging or len(recent) < 3 or i - last_hedge[0] < 8:
+        if not hedging or i - last_hedge[0] < 8:
             return fut.result(), False
+        if len(recent) < 3:
+            # no history yet -- with several ranks a rank only searches the datasets it owns, so it may never have
+            # one (found by the eight-rank executor test): the measured cost model of `_search_workers` stands in,
+            # generously (x 1.5)
+            gain = {1: 1.0, 2: 1.73, 4: 3.05, 8: 4.25, 16: 5.7}
+            th = max(1, fill_team if i == 0 else team)
+            recent = [1.5e-3 * (0.3 + 3.2 * (plan.n_out / 8192.0) / gain[max(k_ for k_ in gain if k_ <= th)])]
         typical = sorted(recent)[len(recent) // 2]
         wait = ev["t_exchanged"] + 2.0 * typical + 0.5e-3 - time.perf_counter()
         try:
@@ -626,6 +728,11 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         """Selection of dataset j -> (exchange) -> its search, inline or on a worker."""
         ev = events[j]
         ev["t_start"] = time.perf_counter()
+        on_dev = use_dev and j >= cpu_fill
+        if on_dev and exchange is None:  # queued behind its selection stage already (guess): nothing to wait for
+            ev["t_exchanged"] = ev["t_start"]
+            pending[j] = (None, ("dev", dev_seq.pop(j)), None)
+            return
         amax, flat, sl = sel[j % ring].wait()  # (largest L1 norm, guessed row * n + arg-max of its fp64 spectrum, spectrum)
         gflat, mine, owner = rank_offset_rows * n + flat, True, 0
         if exchange is not None:  # the guess is global too: the rank with the largest norm owns it
@@ -635,6 +742,9 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), amax)
         res.owner, res.mine = owner, mine
         fut = None
+        if mine and on_dev:  # several ranks: the owner of the winning row queues the search kernel
+            pending[j] = (res, ("dev", launch_dev_search(j)), (sl, int(k), res.pivot))
+            return
         if mine:
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run
             # three (four) at a time and have as many device periods each
@@ -694,7 +804,10 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         ev = events[i]
         # keep the guess kernels g_ahead and the searches s_ahead datasets in front; while the pipeline fills, every
         # search starts right behind its own guess (the first main pass waits for the first search)
-        while started < min(n_sets - 1, i + s_ahead):
+        # (device engine: a search is started as soon as its selection stage is queued -- one rank -- or has ended --
+        # several ranks, whose exchange needs the stage's result: one dataset behind the newest guess)
+        s_look = s_ahead if not use_dev else (g_ahead if exchange is None else max(s_ahead, g_ahead - 1))
+        while started < min(n_sets - 1, i + s_look):
             while guessed < min(n_sets - 1, started + 1):
                 guessed += 1
                 guess(guessed)
@@ -705,7 +818,14 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             guess(guessed)
         res, fut, search_args = pending.pop(i)
         ev["t_collect"] = time.perf_counter()
-        if fut is not None:
+        if isinstance(fut, tuple):  # a search kernel
+            p0, p1, k, nfev, fun, timing, hedged = collect_dev(i, fut[1], ev)
+            if res is None:  # one rank: the record is the first the host hears of this dataset's winner
+                slot = bufs["sel_slots"][b]
+                gflat = (rank_offset_rows + int(slot[1].item()) // n) * n + k
+                res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), float(slot[0].item()) ** 0.5)
+            res.p0, res.p1, res.nfev, res.fun, res.timing, res.hedged = p0, p1, nfev, fun, timing, hedged
+        elif fut is not None:
             if pool is not None:
                 (p0, p1, opt), res.hedged = collect(i, fut, search_args, ev)
                 if "t_search_end" in ev and "t_search_begin" in ev:
