@@ -275,6 +275,17 @@ int xm_search_launch(const void* slice, int n, double c0, double cstep, double x
 int xm_search_eval(const void* slice, int n, double c0, double cstep, double x_range, int target_idx, int p0_only,
                    const double* xs, int count, double* fs, void* stream);
 
+/* ---- streams with a partition of the chip.  A search kernel (above) needs a whole CU's registers for milliseconds,
+ * and the streaming kernels are persistent grids sized to fill every CU: sharing one pool of CUs, searches wait for a
+ * kernel boundary to start and the streaming kernels then find CUs taken (measured: main pass +7 %, stalls of
+ * milliseconds).  So the chip is split: `reserved_cus` CUs -- the first mask bits, i.e. spread round-robin over the
+ * eight XCDs -- belong to the search streams (partition 1), the rest to the compute stream (partition 0).  Persistent
+ * launches size their grids by the CUs of the stream they are given.  The stream's device is the current one. */
+int xm_stream_create(void** stream, int reserved_cus, int partition);
+int xm_stream_destroy(void* stream);
+/* CUs `stream` may use (all of the device's for an ordinary stream); negative xm_status on failure */
+int xm_stream_cus(void* stream);
+
 /* ---- (e) multi-GPU: publication primitives of the one-node O(1) exchange (xmris_amd/sharding.py::ShmExchange; the
  * global arg-max and the one (p0, p1) of phasing.py:229, 276-290 cross the ranks through a shared-memory page).  HOST
  * pointers.  The payload of a slot is written with plain stores, its sequence word with a release store, and readers

@@ -211,6 +211,13 @@ def install(monkeypatch=None):
     put(device, "guess_supported", lambda *a, **k: True)
     put(device, "ramp_native", lambda *a, **k: True)
     put(device, "_require_device", lambda x: None)
+    import contextlib
+    import types
+
+    put(device, "chip_partition", lambda dev_, reserved, n_search: types.SimpleNamespace(
+        compute=FakeStream(), search=[FakeStream() for _ in range(n_search)]))
+    put(device, "replacement_search_stream", lambda dev_, streams: FakeStream())
+    put(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     put(torch.cuda, "Event", FakeEvent)
     put(torch.cuda, "Stream", FakeStream)
     put(torch.cuda, "current_stream", lambda device=None: FakeStream())

@@ -74,6 +74,9 @@ SIGNATURES = {
     "xm_search_launch": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _i, _u, ctypes.c_double, _i,
                               ctypes.c_uint64, _p, _p]),
     "xm_search_eval": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _i, _p, _i, _p, _p]),
+    "xm_stream_create": (_i, [_p, _i, _i]),
+    "xm_stream_destroy": (_i, [_p]),
+    "xm_stream_cus": (_i, [_p]),
     "xm_atomic_load_acquire_i64": (_l, [_p]),
     "xm_atomic_store_release_i64": (None, [_p, _l]),
     "xm_atomic_wait_all_ge_i64": (_i, [_p, _i, _i, _l, _i]),

@@ -226,7 +226,86 @@ int xm_version(void) { return XM_VERSION_NUM; }
 
 const char* xm_last_error_string(void) { return g_err.c_str(); }
 
+// ------------------------------------------------------------------------------------------------
+// Streams with a partition of the chip (hipExtStreamCreateWithCUMask).  Mask bit i is CU slot i / 8 of XCD i % 8
+// (probed: tools/cu_mask_probe.hip), so the first R bits are R CUs spread evenly over the eight XCDs.
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_stream_mu;
+static std::map<hipStream_t, int> g_stream_cus;
+
+int xm_stream_cu_count(hipStream_t st, int* cus) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto it = g_stream_cus.find(st);
+    if (it != g_stream_cus.end()) {
+      *cus = it->second;
+      return XM_OK;
+    }
+  }
+  int dev = 0, total = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+  int n = total;
+  if (st != nullptr) {
+    uint32_t mask[16] = {0};
+    const int words = (total + 31) / 32 < 16 ? (total + 31) / 32 : 16;
+    if (hipExtStreamGetCUMask(st, (uint32_t)words, mask) == hipSuccess) {
+      int c = 0;
+      for (int w = 0; w < words; ++w) c += __builtin_popcount(mask[w]);
+      if (c > 0 && c <= total) n = c;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  g_stream_cus[st] = n;
+  *cus = n;
+  return XM_OK;
+}
+
+extern "C" int xm_stream_create(void** stream, int reserved_cus, int partition) {
+  if (!stream || reserved_cus < 0 || (partition != 0 && partition != 1)) return fail(XM_ERR_INVALID_ARG, "xm_stream_create: bad argument");
+  int dev = 0, total = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+  if (reserved_cus >= total || (partition == 1 && reserved_cus == 0)) return fail(XM_ERR_INVALID_ARG, "xm_stream_create: bad partition");
+  const int words = (total + 31) / 32;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int i = 0; i < total; ++i) {
+    const bool reserved = i < reserved_cus;
+    if (reserved == (partition == 1)) mask[i / 32] |= 1u << (i % 32);
+  }
+  hipStream_t st = nullptr;
+  HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus[st] = partition == 1 ? reserved_cus : total - reserved_cus;
+  }
+  *stream = (void*)st;
+  return XM_OK;
+}
+
+extern "C" int xm_stream_destroy(void* stream) {
+  if (!stream) return XM_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus.erase((hipStream_t)stream);
+  }
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return XM_OK;
+}
+
+extern "C" int xm_stream_cus(void* stream) {
+  int cus = 0;
+  const int rc = xm_stream_cu_count((hipStream_t)stream, &cus);
+  return rc ? rc : cus;
+}
+
 int xm_clear_cache(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus.clear();
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_tables) (void)hipFree(kv.second);
   g_tables.clear();

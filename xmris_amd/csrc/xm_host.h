@@ -68,27 +68,36 @@ int xm_queue_slot(unsigned** out);
 // e^{i (phase0 + dphase k)}, k < n, into `table` (device, storage precision of `dtype`), fp64 sincos per entry
 int xm_ramp_table_async(void* table, int n, double phase0, double dphase, int dtype, hipStream_t st);
 
-// Grid of a persistent kernel = CUs x resident workgroups per CU.  The occupancy query and the dynamic-LDS opt-in
-// run once per kernel instantiation and device, under a lock (the launchers are re-entrant).
+// CUs a stream may use: the population count of its CU mask (all CUs for an ordinary stream; xm_stream_create makes
+// streams with a partition of the chip).  Cached per stream handle.
+extern "C" int xm_stream_cu_count(hipStream_t st, int* cus);  // (C linkage: defined among the ABI functions)
+
+// Grid of a persistent kernel = CUs of its stream x resident workgroups per CU.  The occupancy query and the
+// dynamic-LDS opt-in run once per kernel instantiation and device, under a lock (the launchers are re-entrant).
 struct XmResidency {
   std::mutex mu;
-  int blocks[16] = {0};
+  int blocks[16] = {0};  // resident workgroups per CU
 };
 template <class K>
-int xm_resident_blocks(XmResidency& r, K kern, int nt, size_t lds, int* out) {
+int xm_resident_blocks(XmResidency& r, K kern, int nt, size_t lds, int* out, hipStream_t st = nullptr) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return xm_fail(XM_ERR_INVALID_ARG, "device ordinal out of range");
-  std::lock_guard<std::mutex> lk(r.mu);
-  if (r.blocks[dev] == 0) {
-    if (lds > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nt, lds));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (per_cu < 1) per_cu = 1;
-    r.blocks[dev] = per_cu * cus;
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.blocks[dev] == 0) {
+      if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int q = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, nt, lds));
+      r.blocks[dev] = q < 1 ? 1 : q;
+    }
+    per_cu = r.blocks[dev];
   }
-  *out = r.blocks[dev];
+  int cus = 0;
+  const int rc = xm_stream_cu_count(st, &cus);
+  if (rc) return rc;
+  *out = per_cu * cus;
   return XM_OK;
 }

@@ -24,7 +24,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
                      ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int));
   static XmResidency res;
   int resident = 0;
-  rc = xm_resident_blocks(res, k_zf2d<PL, MODE>, PL::NT, lds, &resident);
+  rc = xm_resident_blocks(res, k_zf2d<PL, MODE>, PL::NT, lds, &resident, st);
   if (rc) return rc;
   // one row (64 KiB in + 128 KiB out) per ticket
   A.queue_chunk = 1;

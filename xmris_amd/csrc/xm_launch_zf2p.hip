@@ -28,7 +28,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
                      ((size_t)PL::NT / XM_WAVE + 2) * (sizeof(T) + sizeof(int)) + (CAND ? zf2p_cand_lds_bytes() : 0);
   static XmResidency res;
   int resident = 0;
-  rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident);
+  rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident, st);
   if (rc) return rc;
   // rows per ticket: about 96 KiB of traffic per chunk (the hot shape's row: 1 -- measured: 2 rows per ticket cost it
   // 12 %), so that a launch at full speed draws at most ~60 of the ~90 tickets per microsecond one counter sustains

@@ -591,3 +591,63 @@ def search_eval(slice_c128, axis, xs, target_idx: int = -1, p0_only: bool = Fals
               float(axis[2]), int(target_idx), int(bool(p0_only)), xs_t.data_ptr(), int(xs_t.shape[0]), fs.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     return fs.cpu().numpy()
+
+
+class ChipPartition:
+    """`xm_stream_create`: one compute stream that owns all CUs but `reserved`, and `n_search` streams that own the
+    reserved ones (spread over the eight XCDs), as torch stream objects.  Kept for the life of the process."""
+
+    def __init__(self, device, reserved: int, n_search: int):
+        import ctypes
+
+        torch = _torch()
+        self.device, self.reserved = device, int(reserved)
+        self._handles = []
+
+        def make(partition):
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.call("xm_stream_create", ctypes.byref(h), int(reserved), partition)
+            self._handles.append(h.value)
+            return torch.cuda.ExternalStream(h.value, device=device)
+
+        self.compute = make(0)
+        self.search = [make(1) for _ in range(int(n_search))]
+
+    def another_search_stream(self):
+        import ctypes
+
+        h = ctypes.c_void_p()
+        with _torch().cuda.device(self.device):
+            _lib.call("xm_stream_create", ctypes.byref(h), self.reserved, 1)
+        self._handles.append(h.value)
+        st = _torch().cuda.ExternalStream(h.value, device=self.device)
+        self.search.append(st)
+        return st
+
+
+_PARTITIONS = {}
+
+
+def chip_partition(device, reserved: int, n_search: int) -> ChipPartition:
+    torch = _torch()
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(reserved))
+    part = _PARTITIONS.get(key)
+    if part is None:
+        part = _PARTITIONS[key] = ChipPartition(device, reserved, n_search)
+    while len(part.search) < n_search:
+        part.another_search_stream()
+    return part
+
+
+def replacement_search_stream(device, partition_streams):
+    """A fresh stream for searches (one whose kernel is still running was retired): of the search partition when the
+    chip is split, an ordinary one otherwise."""
+    torch = _torch()
+    if partition_streams is None:
+        return torch.cuda.Stream(device=device)
+    for part in _PARTITIONS.values():
+        if partition_streams and partition_streams[0] in part.search:
+            return part.another_search_stream()
+    return torch.cuda.Stream(device=device)

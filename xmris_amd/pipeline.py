@@ -485,6 +485,47 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
         else:
             workers, use_dev, dev_ahead = 2, False, 0
     s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
+    cpu_fill = min(n_sets, s_ahead + 1) if use_dev else n_sets
+    use_dev = use_dev and cpu_fill < n_sets
+    eng = dict(workers=workers, team=team, use_dev=use_dev, dev_ahead=dev_ahead, est_ms=est_ms if use_dev else 0.0,
+               axis=axis, search_streams=None)
+    args = (inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width, p0_only, trace,
+            polish, eng)
+    if not use_dev or os.environ.get("XM_SEARCH_PARTITION", "1") == "0":  # (tuning switch: searches share the chip)
+        return _spec_loop(*args)
+    # Search kernels need a whole CU's registers for milliseconds, the streaming kernels are persistent grids sized to
+    # fill every CU: sharing one pool, a search waits for a kernel boundary to start and the main pass then finds CUs
+    # taken (measured: main pass +7 %, stalls of milliseconds).  So the chip is split for the duration of the call --
+    # `reserved` CUs, spread over the eight XCDs, for the searches; the streaming kernels run on a stream that owns
+    # the rest and size their grids by it (`xm_stream_create`).
+    reserved = int(os.environ.get("XM_SEARCH_CUS", "0")) or int(min(32, 8 * -(-max(dev_ahead, 1) // 8)))
+    part = dev.chip_partition(x0.device, reserved, n_search=min(16, max(dev_ahead, 1) + 2))
+    eng["search_streams"] = part.search
+    caller = torch.cuda.current_stream(x0.device)
+    part.compute.wait_stream(caller)
+    try:
+        with torch.cuda.stream(part.compute):
+            return _spec_loop(*args)
+    finally:
+        caller.wait_stream(part.compute)
+
+
+def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width, p0_only, trace,
+               polish, eng):
+    """The software pipeline of `_run_stream_speculative` (engine and look-ahead chosen there)."""
+    import os
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    n_sets, n = len(inputs), plan.n_out
+    x0 = inputs[0]
+    nb = x0.shape[0]
+    rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
+    workers, team, use_dev, dev_ahead, est_ms, axis = (eng["workers"], eng["team"], eng["use_dev"], eng["dev_ahead"],
+                                                        eng["est_ms"], eng["axis"])
+    s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
     # (round 3: the selection stage of dataset j on a stream of its own beside the coarse spectra of dataset j + 1,
     # gated so that it never shares the chip with a main pass, hides nothing -- the coarse-spectra kernel fills the
     # chip, 1.20 vs 1.20 ms per step; let loose beside the main kernel it costs 6 %.  Only the winner's fp64 spectrum
@@ -615,6 +656,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             dsearch = plan.extra[("dev_search", ring)] = dict(
                 recs=[dev.new_search_record() for _ in range(ring)],
                 streams=[torch.cuda.Stream(device=x0.device) for _ in range(min(ring, 16))], seq=[0], retired=[])
+        if eng["search_streams"] is not None:  # the search partition of the chip (see _run_stream_speculative)
+            dsearch["streams"] = list(eng["search_streams"])
 
     def launch_dev_search(j, after=None):
         """`xm_search_launch` for dataset j on a side stream; returns the sequence number its record will carry."""
@@ -646,7 +689,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                 # ends; the stream's later searches would queue behind it)
                 dsearch["retired"].append((rec, dsearch["streams"][i % len(dsearch["streams"])]))
                 dsearch["recs"][b] = dev.new_search_record()
-                dsearch["streams"][i % len(dsearch["streams"])] = torch.cuda.Stream(device=x0.device)
+                dsearch["streams"][i % len(dsearch["streams"])] = dev.replacement_search_stream(x0.device, eng["search_streams"])
                 return p0, p1, k, int(opt.nfev), float(opt.fun), {"generations_ms": 1e3 * opt.get("t_generations", 0.0),
                                                                  "polish_ms": 1e3 * opt.get("t_polish", 0.0)}, True
             if blocking:  # few cores per rank: do not spin beside another rank's launch thread
@@ -818,7 +861,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             guess(guessed)
         res, fut, search_args = pending.pop(i)
         ev["t_collect"] = time.perf_counter()
-        if isinstance(fut, tuple):  # a search kernel
+        if isinstance(fut, tuple) and len(fut) == 2 and fut[0] == "dev":  # a search kernel
             p0, p1, k, nfev, fun, timing, hedged = collect_dev(i, fut[1], ev)
             if res is None:  # one rank: the record is the first the host hears of this dataset's winner
                 slot = bufs["sel_slots"][b]
