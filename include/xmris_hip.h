@@ -86,6 +86,16 @@ int xm_zero_fill(const void* in, void* out, int64_t n_batch, int n_in, int n_out
 int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, int n, int dtype,
                void* stream);
 
+/* A1 + A2 in ONE pass  (processing/fid.py:251 `da.pad(...)` followed by fid.py:136-139 `da * exp(-pi lb t)`):
+ *   out[b, j] = in[b, j - pad_left] * window[j]  for pad_left <= j < pad_left + n_in,  +0 elsewhere.
+ * The fused zero-fill + apodisation launch for chains that stop before the FFT: 16-byte loads of the FID axis, the
+ * window staged through the LDS, nontemporal 16-byte stores, rows handed out by a device-scope counter.  `window`:
+ * n_out reals of the OUTPUT precision.  `out_dtype` = `in_dtype`, or XM_C128 for XM_C64 rows (numpy's promotion when a
+ * complex64 FID meets the float64 window, fid.py:136-139: each product is then the exact complex128 product numpy
+ * computes).  n_out * sizeof(real) <= 96 KiB.  in != out. */
+int xm_zf_apod(const void* in, int64_t in_row_stride, void* out, const void* window, int64_t n_batch, int n_in, int n_out,
+               int pad_left, int in_dtype, int out_dtype, void* stream);
+
 /* A3/A4/A5  fft / ifft / fftshift folded  (processing/fourier.py:153, 210, 31, 57).
  * out[b, (m + s_out) mod n] = scale * sum_k in[b, (k - s_in) mod n] * e^{-+2 pi i k m / n}. */
 /* 1 when xm_pipeline_fused(_ramp) accepts XM_AMAX_GLOBAL_KEY for this geometry and dtype, else 0. */

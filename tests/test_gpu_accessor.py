@@ -360,3 +360,35 @@ def test_host_resident_fids_take_the_chunked_path(xm, oracle, monkeypatch, dtype
     assert chain.dims == oc.dims and set(chain.attrs) == set(oc.attrs)
     assert abs(chain.attrs["phase_p0"] - oc.attrs["phase_p0"]) < 1e-6 and abs(chain.attrs["phase_p1"] - oc.attrs["phase_p1"]) < 1e-6
     np.testing.assert_allclose(chain.values, oc.values, rtol=0, atol=1e-9 * np.abs(oc.values).max())
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("position", ["end", "symmetric"])
+def test_chain_that_stops_before_the_fft_is_one_launch(xm, oracle, monkeypatch, dtype, position):
+    """`apodize_exp(zero_fill(fid))` asked for its values (north_star's "fused zero-fill + exponential-apodisation
+    kernel"; reference fid.py:251 then fid.py:136-139): ONE launch of `xm_zf_apod` on the root -- neither staged kernel
+    runs, no zero-filled intermediate exists -- with the oracle's dims / coords / attrs / dtype and values: the padding
+    is exactly zero, the samples are numpy's products bit for bit (complex128 after numpy's promotion)."""
+    from xmris_amd import device as dev
+
+    nv, nt, n_out = 6, 512, 1280
+    rng = np.random.default_rng(31)
+    t = np.arange(nt) * 2e-4
+    x = (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt))).astype(dtype)
+    a, o = _pair(xm, oracle, x, ("voxel", "time"), {"voxel": np.arange(nv), "time": t}, {"MHz": 120.0})
+    calls = {"zero_fill": 0, "apodize": 0, "zf_apod": 0}
+    for name in calls:
+        real = getattr(dev, name)
+        monkeypatch.setattr(dev, name, (lambda real, name: lambda *a_, **k_: (calls.__setitem__(name, calls[name] + 1), real(*a_, **k_))[1])(real, name))
+    for apod, oapod, kw in ((lambda z: z.xmr.apodize_exp(lb=4.0), lambda z: oracle.apodize_exp(z, lb=4.0), None),
+                            (lambda z: z.xmr.apodize_lg(lb=1.0, gb=2.0), lambda z: oracle.apodize_lg(z, lb=1.0, gb=2.0), None)):
+        before = dict(calls)
+        zf = a.xmr.zero_fill(target_points=n_out, position=position)
+        ap = apod(zf)
+        assert zf.is_deferred and ap.is_deferred
+        ref = oapod(oracle.zero_fill(o, target_points=n_out, position=position))
+        vals = ap.values
+        assert {k: calls[k] - before[k] for k in calls} == {"zero_fill": 0, "apodize": 0, "zf_apod": 1}, calls
+        assert zf.is_deferred  # the zero-filled intermediate was never materialised
+        assert vals.dtype == np.complex128 and np.array_equal(vals.view(np.uint8), np.asarray(ref.values).view(np.uint8))
+        _same(ap, ref, 1e-300)

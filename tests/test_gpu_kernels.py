@@ -812,3 +812,36 @@ def test_randomised_geometries_of_the_fused_entry_point(dev, oracle):
                 mag = np.abs(spec)
                 # the device compares in the storage precision: accept any index whose magnitude ties the maximum there
                 assert np.all(mag[np.arange(nb), idx] >= mag.max(axis=1) * (1 - 30 * tol)), tag
+
+
+@pytest.mark.parametrize("case", [
+    # (n_batch, n_in, n_out, pad_left, in dtype, promote)
+    (9, 1024, 2048, 0, "complex64", False), (9, 1024, 2048, 0, "complex64", True), (9, 1024, 2048, 0, "complex128", False),
+    (5, 32, 128, 48, "complex64", True),                      # symmetric zero fill (fid.py:243-246)
+    (3, 1023, 2048, 0, "complex64", False),                   # odd length: rows leave the 16-byte grid (one element per lane)
+    (3, 1023, 2047, 511, "complex64", True), (4, 100, 101, 1, "complex128", False),
+    (700, 4096, 8192, 0, "complex64", False),                 # more rows than resident workgroups: the row queue
+    (1, 2, 4, 0, "complex64", True), (2, 4096, 4096, 0, "complex128", False),  # (no zero fill at all: a plain window)
+])
+def test_zero_fill_apodize_one_launch(dev, case):
+    """`xm_zf_apod` (fid.py:251 followed by fid.py:136-139 in one pass): the padding is +0 bit for bit, the samples are
+    numpy's products -- complex times real is two correctly rounded products in either implementation, so bit for bit
+    as well -- for both positions, both precisions, numpy's complex64 -> complex128 promotion, rows on and off the
+    16-byte grid, and more rows than the persistent grid holds."""
+    import torch
+
+    nb, n_in, n_out, pad_left, dtype, promote = case
+    x = _rand((nb, n_in), dtype, seed=n_in + nb)
+    w = np.exp(-np.pi * 5.0 * (np.arange(n_out) - pad_left) / 5000.0)
+    got = dev.zf_apod(dev.to_device(x), n_out, pad_left, w, promote=promote)
+    torch.cuda.synchronize()
+    out_c128 = promote or dtype == "complex128"
+    assert got.dtype == (torch.complex128 if out_c128 else torch.complex64) and tuple(got.shape) == (nb, n_out)
+    wd = w if out_c128 else w.astype(np.float32)
+    ref = np.zeros((nb, n_out), dtype=np.complex128 if out_c128 else np.complex64)
+    ref[:, pad_left:pad_left + n_in] = x.astype(ref.dtype) * wd[pad_left:pad_left + n_in][None, :]
+    g = got.cpu().numpy()
+    assert np.array_equal(g.view(np.uint8), ref.view(np.uint8))  # signed zeros and all
+    # a second launch on the same queue slot ring (the last workgroup out must have left the counters zero)
+    again = dev.zf_apod(dev.to_device(x), n_out, pad_left, w, promote=promote).cpu().numpy()
+    assert np.array_equal(again.view(np.uint8), ref.view(np.uint8))

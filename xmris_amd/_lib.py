@@ -44,6 +44,7 @@ SIGNATURES = {
     "xm_zero_fill": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "xm_apodize": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "xm_fft1d_batched": (_i, [_p, _p, _l, _i, _u, _i, _p]),
+    "xm_zf_apod": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "xm_roll": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "xm_phase_apply": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "xm_absmax_rows": (_i, [_p, _l, _i, _p, _p, _i, _p]),

@@ -5,6 +5,7 @@
 #include "xm_als.h"
 #include "xm_kernels.h"
 #include "xm_plans.h"
+#include "xm_zfapod.h"
 
 #include <cmath>
 #include <cstdio>
@@ -220,6 +221,46 @@ static int check_common(const void* in, int64_t n_batch, int n, int dtype) {
 // ------------------------------------------------------------------------------------------------
 // extern "C"
 // ------------------------------------------------------------------------------------------------
+// A1 + A2 in one pass (fid.py:251 then :136-139), see xm_zfapod.h
+template <class TI, class TO>
+static int launch_zf_apod(const void* in, int64_t in_stride, void* out, const void* window, int64_t n_batch, int n_in,
+                          int n_out, int pad_left, hipStream_t st) {
+  ZfApodArgs<TI, TO> A;
+  A.in = (const Cx<TI>*)in;
+  A.out = (Cx<TO>*)out;
+  A.window = (const TO*)window;
+  A.in_stride = in_stride;
+  A.n_batch = n_batch;
+  A.n_in = n_in;
+  A.n_out = n_out;
+  A.pad_left = pad_left;
+  const size_t lds = (size_t)n_out * sizeof(TO);
+  const size_t esz = sizeof(Cx<TI>);
+  // 16-byte lanes: rows of both arrays on 16-byte boundaries, and (8-byte elements) whole pairs inside the samples
+  const bool vec = (reinterpret_cast<size_t>(in) % 16 == 0) && (reinterpret_cast<size_t>(out) % 16 == 0) &&
+                   ((size_t)in_stride * esz) % 16 == 0 && ((size_t)n_out * sizeof(Cx<TO>)) % 16 == 0 &&
+                   (esz == 16 || (pad_left % 2 == 0 && n_in % 2 == 0 && n_out % 2 == 0));
+  int rc = xm_queue_slot(&A.queue);
+  if (rc) return rc;
+  int resident = 0;
+  if (vec) {
+    static XmResidency res;
+    rc = xm_resident_blocks(res, k_zf_apod<TI, TO, true>, 256, lds, &resident, st);
+    if (rc) return rc;
+    const long long blocks = n_batch < resident ? n_batch : resident;
+    hipLaunchKernelGGL((k_zf_apod<TI, TO, true>), dim3((unsigned)blocks), dim3(256), lds, st, A);
+  } else {
+    static XmResidency res;
+    rc = xm_resident_blocks(res, k_zf_apod<TI, TO, false>, 256, lds, &resident, st);
+    if (rc) return rc;
+    const long long blocks = n_batch < resident ? n_batch : resident;
+    hipLaunchKernelGGL((k_zf_apod<TI, TO, false>), dim3((unsigned)blocks), dim3(256), lds, st, A);
+  }
+  HIP_TRY(hipGetLastError());
+  return XM_OK;
+}
+
+
 extern "C" {
 
 int xm_version(void) { return XM_VERSION_NUM; }
@@ -370,6 +411,26 @@ int xm_apodize(const void* in, void* out, const void* window, int64_t n_batch, i
                        (Cx<double>*)out, (const double*)window, (long long)n_batch, n);
   HIP_TRY(hipGetLastError());
   return XM_OK;
+}
+
+int xm_zf_apod(const void* in, int64_t in_row_stride, void* out, const void* window, int64_t n_batch, int n_in, int n_out,
+               int pad_left, int in_dtype, int out_dtype, void* stream) {
+  int rc = check_common(in, n_batch, n_in, in_dtype);
+  if (rc) return rc;
+  if (!out || !window || n_out < n_in || pad_left < 0 || pad_left + n_in > n_out || in_row_stride < n_in || in == out)
+    return fail(XM_ERR_INVALID_ARG, "zf_apod: bad pointer or geometry");
+  if ((out_dtype != XM_C64 && out_dtype != XM_C128) || (in_dtype == XM_C128 && out_dtype == XM_C64))
+    return fail(XM_ERR_INVALID_ARG, "zf_apod: the output precision is the input's or complex128");
+  if ((size_t)n_out * (out_dtype == XM_C64 ? 4 : 8) > 96 * 1024)
+    return fail(XM_ERR_UNSUPPORTED_N, "zf_apod: the window does not fit the LDS (use xm_zero_fill + xm_apodize)");
+  if (n_batch == 0) return XM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  DeviceGuard guard(in);
+  if (in_dtype == XM_C64 && out_dtype == XM_C64)
+    return launch_zf_apod<float, float>(in, in_row_stride, out, window, n_batch, n_in, n_out, pad_left, st);
+  if (in_dtype == XM_C64)
+    return launch_zf_apod<float, double>(in, in_row_stride, out, window, n_batch, n_in, n_out, pad_left, st);
+  return launch_zf_apod<double, double>(in, in_row_stride, out, window, n_batch, n_in, n_out, pad_left, st);
 }
 
 int xm_phase_apply(const void* in, void* out, const void* phase_table, int64_t n_batch, int n, int dtype,

@@ -1,0 +1,110 @@
+// k_zf_apod -- zero fill + apodisation in ONE pass over the FIDs (reference processing/fid.py:251 `da.pad(...)`
+// followed by fid.py:136-139 `da * exp(-pi lb t)`): out[b, j] = in[b, j - pad_left] * window[j] inside the acquired
+// samples, 0 elsewhere.  The chain `apodize_*(zero_fill(fid))` stopped before the FFT used to be two launches with a
+// full-size intermediate (32 + 64 + 64 + 64 KiB per 4096 -> 8192 complex64 row instead of 32 + 64).
+//
+// A pure streaming kernel, shaped like what `tools/stream_lab.hip` measured as this chip's best for a 1 : 2 read : write
+// row pattern: persistent 256-thread workgroups, 16-byte loads and 16-byte NONTEMPORAL stores, a row per ticket from a
+// device-scope counter (static splits lose ~10 % to the workgroups' unequal speeds), the next ticket claimed while the
+// current row's loads are in flight.  The window is staged through the LDS once per workgroup -- coalesced 16-byte
+// reads -- and, where a thread's columns fit (n_out <= 64 x 256 elements... 32 weights per thread), kept in registers
+// for the whole launch.  TI / TO: storage precision of the input / output (complex64 rows times a float64 window give
+// complex128, numpy's promotion, fid.py:136-139).  gfx950 only.
+#pragma once
+#include "xm_common.h"
+
+typedef float xm_f4 __attribute__((ext_vector_type(4)));
+
+template <class TI, class TO>
+struct ZfApodArgs {
+  const Cx<TI>* in;
+  Cx<TO>* out;
+  const TO* window;  // n_out weights of the OUTPUT precision
+  unsigned* queue;   // {head, done}, both 0 at launch; the last workgroup out leaves them 0
+  long long in_stride, n_batch;
+  int n_in, n_out, pad_left;
+};
+
+// VEC: every row of the input and the output is 16-byte aligned and pad_left / n_in are even for 8-byte elements, so a
+// lane moves 16 bytes of input per step.  Otherwise: one element per lane and step (any geometry).
+template <class TI, class TO, bool VEC>
+__global__ __launch_bounds__(256) void k_zf_apod(ZfApodArgs<TI, TO> A) {
+  constexpr int NT = 256;
+  constexpr int EPL = VEC ? (int)(16 / sizeof(Cx<TI>)) : 1;  // input elements per lane and step (2 x c64, 1 x c128)
+  extern __shared__ __attribute__((aligned(16))) char xm_smem[];
+  TO* wl = reinterpret_cast<TO*>(xm_smem);  // the window, n_out weights
+  __shared__ long long ticket[2];
+  const int t = (int)threadIdx.x;
+  for (int j = t; j < A.n_out; j += NT) wl[j] = A.window[j];
+  long long row = blockIdx.x;  // the first round is static, then tickets
+  if (t == 0) ticket[0] = (long long)gridDim.x + (long long)atomicAdd(A.queue, 1u);
+  __syncthreads();
+  const int per_step = NT * EPL;
+  for (int it = 0; row < A.n_batch; ++it) {
+    // the row after this one was claimed an iteration ago; the one after that is claimed now, while this row's
+    // loads are in flight (two slots: this iteration's readers and its writer never meet; one barrier per row)
+    const long long nxt = ticket[it & 1];
+    if (t == 0) ticket[(it + 1) & 1] = (long long)gridDim.x + (long long)atomicAdd(A.queue, 1u);
+    const Cx<TI>* __restrict__ irow = A.in + row * A.in_stride;
+    Cx<TO>* __restrict__ orow = A.out + row * (long long)A.n_out;
+    for (int j0 = t * EPL; j0 < A.n_out; j0 += per_step) {
+      const int k = j0 - A.pad_left;  // input index of the first element
+      Cx<TO> y[EPL];
+      if (k >= 0 && k + EPL <= A.n_in) {
+        Cx<TI> v[EPL];
+        if constexpr (VEC && EPL == 2) {
+          const xm_f4 q = __builtin_nontemporal_load(reinterpret_cast<const xm_f4*>(irow + k));
+          v[0] = mk<TI>(q.x, q.y);
+          v[1] = mk<TI>(q.z, q.w);
+        } else if constexpr (VEC) {
+          const xm_d2 q = __builtin_nontemporal_load(reinterpret_cast<const xm_d2*>(irow + k));
+          v[0] = mk<TI>(q.x, q.y);
+        } else {
+          v[0] = irow[k];
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const TO w = wl[j0 + e];
+          y[e] = mk<TO>((TO)v[e].re * w, (TO)v[e].im * w);  // complex times real: two products, as numpy's
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int ke = k + e;
+          const bool in_range = ke >= 0 && ke < A.n_in && j0 + e < A.n_out;
+          const Cx<TI> v = in_range ? irow[ke] : mk<TI>(TI(0), TI(0));
+          const TO w = in_range ? wl[j0 + e] : TO(0);
+          y[e] = mk<TO>((TO)v.re * w, (TO)v.im * w);
+          if (!in_range) y[e] = mk<TO>(TO(0), TO(0));  // the padding is +0, whatever the window holds there
+        }
+      }
+      if constexpr (VEC && sizeof(Cx<TO>) == 8) {  // two complex64 results: one 16-byte store
+        xm_f4 q;
+        q.x = (float)y[0].re;
+        q.y = (float)y[0].im;
+        q.z = (float)y[1].re;
+        q.w = (float)y[1].im;
+        __builtin_nontemporal_store(q, reinterpret_cast<xm_f4*>(orow + j0));
+      } else if constexpr (VEC) {  // complex128 results: a 16-byte store each
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          xm_d2 q;
+          q.x = (double)y[e].re;
+          q.y = (double)y[e].im;
+          __builtin_nontemporal_store(q, reinterpret_cast<xm_d2*>(orow + j0 + e));
+        }
+      } else {
+        if (j0 < A.n_out) orow[j0] = y[0];
+      }
+    }
+    __syncthreads();
+    row = nxt;
+  }
+  if (t == 0) {  // the last workgroup out leaves the counters zero for the next launch
+    __threadfence();
+    if (atomicAdd(A.queue + 1, 1u) == gridDim.x - 1) {
+      A.queue[0] = 0u;
+      A.queue[1] = 0u;
+    }
+  }
+}

@@ -187,6 +187,34 @@ def apodize(x, axis: int, window):
     return restore(out)
 
 
+def zf_apod_supported(n_out: int, out_complex128: bool) -> bool:
+    """True when `zf_apod` takes this output length (its window must fit the LDS)."""
+    return int(n_out) * (8 if out_complex128 else 4) <= 96 * 1024
+
+
+def zf_apod(x2, n_out: int, pad_left: int, window, promote: bool = False):
+    """fid.py:251 + fid.py:136-139 in one launch (`xm_zf_apod`): ``x2`` = [n_batch, n_in] contiguous rows -> [n_batch,
+    n_out] rows, zero filled and multiplied by `window` (n_out weights, fp64 host values or a device tensor).
+    `promote`: complex64 rows give complex128 results (numpy's promotion against the float64 window)."""
+    _require_device(x2)
+    torch = _torch()
+    if x2.dim() != 2 or not x2.is_contiguous():
+        raise ValueError("zf_apod expects a contiguous [n_batch, n_in] tensor")
+    nb, n_in = x2.shape
+    out_dt = torch.complex128 if (promote or x2.dtype == torch.complex128) else torch.complex64
+    rd = torch.float64 if out_dt == torch.complex128 else torch.float32
+    if isinstance(window, torch.Tensor):
+        w = window.to(device=x2.device, dtype=rd).contiguous()
+    else:
+        w = torch.from_numpy(np.ascontiguousarray(np.asarray(window, dtype=np.float64))).to(device=x2.device, dtype=rd)
+    if w.numel() != n_out:
+        raise ValueError(f"window has {w.numel()} points, the zero-filled axis has {n_out}")
+    out = torch.empty((nb, n_out), dtype=out_dt, device=x2.device)
+    _lib.call("xm_zf_apod", x2.data_ptr(), n_in, out.data_ptr(), w.data_ptr(), nb, n_in, int(n_out), int(pad_left),
+              _dtype_code(x2), _lib.XM_C128 if out_dt == torch.complex128 else _lib.XM_C64, _stream(x2))
+    return out
+
+
 def phase_apply(x, axis: int, table):
     """phasing.py:73 ``da * np.exp(1j * phase_array)`` with a complex table over `axis`."""
     _require_device(x)

@@ -454,7 +454,7 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # than a search, more -- with smaller teams, which use the cores better -- where the host would pace the steps
     workers, team = _search_workers(plan, nb, x0.element_size())
     # ---- search engine ------------------------------------------------------------------------------------------
-    # "device" (default where it applies): the search of a dataset runs as ONE workgroup on a side stream right behind
+    # "device": the search of a dataset runs as ONE workgroup on a side stream right behind
     # the dataset's selection stage (`xm_search_launch`, csrc/xm_search.hip: scipy's generations bit for bit, then the
     # projected-gradient test scipy's polish starts with) -- no host core computes anything, no team spins, and what a
     # shared host does to its threads no longer reaches the device's schedule; a search that does not pass the test is
@@ -464,7 +464,17 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     axis = plan.extra.get("uniform_axis")
     if axis is None:
         axis = plan.extra["uniform_axis"] = dev.uniform_axis(plan.freq) or False
-    use_dev = (os.environ.get("XMRIS_AMD_SEARCH", "device") == "device" and polish == "exact" and method == "acme"
+    # Which one?  Measured on one rank with 16 CPUs (profiles/r04/search_engines.txt): the host engine is FASTER -- a
+    # search kernel needs a whole CU's registers for 2.5-4 ms, so the chip is split (`xm_stream_create`), and the
+    # streaming kernels lose more than the CUs' share (65,536 x 4096 -> 8192: 52.3 vs 48.0 M spectra/s; 16,384 x 2048
+    # -> 4096: 0.35 vs 0.49 ms per dataset).  What the device engine buys is independence from the host: 2 instead of
+    # 6 busy cores, and a schedule that a contended or core-starved host cannot disturb.  "auto" therefore takes it
+    # only where the host cannot carry the searches: fewer than three CPUs per rank of this node.
+    want = os.environ.get("XMRIS_AMD_SEARCH", "auto")
+    if want == "auto":
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        want = "device" if aps._cpu_share() < 3 * local_world else "host"
+    use_dev = (want == "device" and polish == "exact" and method == "acme"
                and overlap and axis is not False and dev.search_supported(n, method, axis[2]))
     dev_ahead = 0
     if use_dev:
@@ -491,6 +501,15 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
                axis=axis, search_streams=None)
     args = (inputs, outputs, plan, exchange, broadcast, rank_offset_rows, overlap, method, peak_width, p0_only, trace,
             polish, eng)
+    if os.environ.get("XM_FORCE_PARTITION") and not use_dev:  # tuning switch: the compute partition without any search kernel
+        part = dev.chip_partition(x0.device, int(os.environ["XM_FORCE_PARTITION"]), n_search=1)
+        caller = torch.cuda.current_stream(x0.device)
+        part.compute.wait_stream(caller)
+        try:
+            with torch.cuda.stream(part.compute):
+                return _spec_loop(*args)
+        finally:
+            caller.wait_stream(part.compute)
     if not use_dev or os.environ.get("XM_SEARCH_PARTITION", "1") == "0":  # (tuning switch: searches share the chip)
         return _spec_loop(*args)
     # Search kernels need a whole CU's registers for milliseconds, the streaming kernels are persistent grids sized to

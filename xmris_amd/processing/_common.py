@@ -95,6 +95,8 @@ def fused_materialise(la: LabeledArray):
     root = node
     # either window (the kernel takes the weights as they are)
     names = ["apodize" if s_[0] in ("apodize_exp", "apodize_lg") else s_[0] for s_ in nodes]
+    if names == ["apodize", "zero_fill"]:  # the chain stops before the FFT: zero fill + window in one launch
+        return _zf_apod_materialise(root, nodes)
     if names not in (["to_spectrum", "apodize", "zero_fill"], ["to_spectrum", "apodize"], ["to_spectrum", "zero_fill"]):
         return None
     steps = {name: s_[1] for name, s_ in zip(names, nodes)}
@@ -122,4 +124,30 @@ def fused_materialise(la: LabeledArray):
         return None  # the staged steps raise the reference's own errors
     x2 = x.reshape(-1, n)
     out = dev.pipeline_fused(x2, n_out, pad_left, window=window).out
+    return out.reshape(tuple(root.shape[:-1]) + (n_out,))
+
+
+def _zf_apod_materialise(root: LabeledArray, nodes):
+    """`apodize_exp | apodize_lg(zero_fill(fid))` asked for its values: `xm_zf_apod` on the root -- one read of the FIDs,
+    one write of the result, no zero-filled intermediate (fid.py:251, 136-139).  None -> the staged steps."""
+    apod, zf = nodes[0][1], nodes[1][1]
+    d0 = apod["dim"]
+    if zf["dim"] != d0 or d0 not in root.dims or root.get_axis_num(d0) != root.ndim - 1:
+        return None
+    if not np.issubdtype(root.dtype, np.complexfloating) or root.ndim < 1:
+        return None
+    x, _ = device_data(root)
+    if not hasattr(x, "detach") or not x.is_contiguous() or x.numel() == 0:
+        return None
+    import os
+
+    import torch
+
+    n = root.sizes[d0]
+    n_out = int(zf["target_points"])
+    pad_left = (n_out - n) // 2 if zf["position"] == "symmetric" else 0
+    promote = x.dtype == torch.complex64 and not os.environ.get("XMRIS_AMD_KEEP_COMPLEX64")
+    if n_out <= n or not dev.zf_apod_supported(n_out, promote or x.dtype == torch.complex128):
+        return None
+    out = dev.zf_apod(x.reshape(-1, n), n_out, pad_left, apod["_weight"], promote=promote)
     return out.reshape(tuple(root.shape[:-1]) + (n_out,))
