@@ -114,7 +114,8 @@ def _rank_main(rank, world, port, engine, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_WORLD_SIZE=str(world), XM_SOLVER_THREADS="1", XMRIS_AMD_SEARCH=engine)
     if engine == "host":
-        os.environ["XM_TEST_SLOW_SEARCH"] = "7,60"  # dataset 7's search naps 60 ms on its owner: started a second time
+        os.environ["XM_HEDGE_SPACING"] = "1"  # (a rank owns every seventh dataset here: the one-in-eight rule would never let it hedge twice)
+        os.environ["XM_TEST_SLOW_SEARCH"] = "7,4000"  # dataset 7's search reaches its owner's search service 4 s late: started a second time
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import _stream_double
@@ -152,7 +153,7 @@ def _rank_main(rank, world, port, engine, q):
 def test_world_8_speculative_executor(monkeypatch, engine):
     """EIGHT ranks (spawned processes, gloo + the shared-memory exchange), 14 datasets, `overlap` on: the winners rotate
     over ranks 1..7 (rank 0 never owns one), two datasets are guessed wrong with the guessed row and the true row on
-    different ranks (cross-rank repair), and with the host engine one search runs 60 ms late and is started a second
+    different ranks (cross-rank repair), and with the host engine one search reaches its service 4 s late and is started a second
     time.  Every rank must return the single-process classic result bit for bit -- (p0, p1), pivot, flat index, and
     its shard of every output -- and all ranks must have made the same number of exchange and broadcast calls."""
     import _stream_double

@@ -645,6 +645,78 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             pool = plan.extra[("search_pool", n_workers)] = ThreadPoolExecutor(max_workers=n_workers + 1,
                                                                               thread_name_prefix="xm-search")
 
+    # The host engine's searches run on NATIVE threads of the library (`xm_hostsearch_submit`: generations + the
+    # projected-gradient test, the result in a record this thread polls) -- a search on a Python thread costs 60-100 us
+    # of interpreter under the lock this thread needs to queue kernels, which is what paced the small configurations.
+    # Python threads remain for the other polish modes ("native" / "numpy": scipy's minimiser in the loop).
+    use_service = polish == "exact" and not os.environ.get("XM_SEARCH_PYTHON_THREADS")
+    hsearch = None
+    if use_service:
+        hsearch = plan.extra.get(("host_search", ring))
+        if hsearch is None:
+            hsearch = plan.extra[("host_search", ring)] = dict(
+                recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)],
+                spare=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(2)], seq=[0])
+        if plan.extra.get("freq_c") is None:
+            plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
+
+    def submit_host_search(j, k, threads, rec):
+        """`xm_hostsearch_submit` of dataset j's slice (pinned, in its selection slot); returns the sequence number."""
+        from . import _lib
+
+        hsearch["seq"][0] += 1
+        seq = hsearch["seq"][0]
+        rec[7] = 0
+        _lib.call("xm_hostsearch_submit", sel[j % ring].h_slice.data_ptr(), n, plan.extra["freq_c"].ctypes.data,
+                  aps.METHODS.index(method), int(k), int(iw), int(bool(p0_only)), 42, 0.01, 1000, int(threads), seq,
+                  rec.data_ptr())
+        return seq
+
+    def collect_host(i, seq, k, ev):
+        """Result of dataset i's search on the service -> (p0, p1, nfev, fun, timing, hedged); a search later than twice
+        the typical time is submitted a second time with the whole team and the first to finish is taken (see `collect`)."""
+        b = i % ring
+        rec = hsearch["recs"][b]
+        recent = (fill_hist if i == 0 else run_hist)[-9:]
+        if len(recent) < 3:  # (see `collect`: no history yet, or -- several ranks -- never)
+            gain = {1: 1.0, 2: 1.73, 4: 3.05, 8: 4.25, 16: 5.7}
+            th = max(1, fill_team if i == 0 else team)
+            # (x 3: a process's first searches also start the service's threads and their teams)
+            recent = [3e-3 * (0.3 + 3.2 * (plan.n_out / 8192.0) / gain[max(k_ for k_ in gain if k_ <= th)]) + 1e-3]
+        typical = sorted(recent)[len(recent) // 2]
+        deadline = ev["t_exchanged"] + 2.0 * typical + 0.5e-3
+        can_hedge = hedging and i - last_hedge[0] >= hedge_gap
+        second, hedged, nap = None, False, 0.0
+        while True:
+            if dev.search_done(rec, seq):
+                break
+            if second is not None and dev.search_done(second[0], second[1]):
+                rec = second[0]
+                break
+            if can_hedge and second is None and time.perf_counter() > deadline:
+                last_hedge[0] = i
+                spare = hsearch["spare"][i & 1]
+                second = (spare, submit_host_search(i, k, fill_team, spare))
+                hedged = True
+            if blocking:
+                nap = min(1e-4, nap + 1e-5)
+                time.sleep(nap)
+        r = dev.read_search_record(rec)
+        hist = fill_hist if i == 0 else run_hist
+        hist.append(1e-6 * r["t_us"][5])
+        del hist[:-16]
+        p0, p1 = r["x"]
+        nfev, fun = r["nfev"] + (1 if p0_only else 2) + 1, r["fun"]
+        timing = {"generations_ms": 1e-3 * r["t_us"][0], "polish_ms": 1e-3 * (r["t_us"][5] - r["t_us"][0])}
+        if r["needs_polish"]:
+            t0 = time.perf_counter()
+            sl = sel[b].h_slice[0].numpy().copy()
+            x, fun, nfev_p, _ = aps.polish_reference(sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+            p0, p1 = float(x[0]), (float(x[1]) if not p0_only else 0.0)
+            nfev = r["nfev"] + nfev_p
+            timing["polish_ms"] = 1e3 * (time.perf_counter() - t0)
+        return p0, (p1 if not p0_only else 0.0), nfev, fun, timing, hedged
+
     def guess(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
         b = j % ring
         ev = events[j]
@@ -755,12 +827,13 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     # device idle behind it) has a history of its own
     run_hist, fill_hist = plan.extra.setdefault("search_run_hist", []), plan.extra.setdefault("fill_run_hist", [])
     last_hedge = [-100]
+    hedge_gap = max(1, int(os.environ.get("XM_HEDGE_SPACING", "8")))  # (tuning / test switch: datasets between two hedges)
 
     def collect(i, fut, args, ev):
         from concurrent.futures import TimeoutError as FutureTimeout
 
         recent = (fill_hist if i == 0 else run_hist)[-9:]
-        if not hedging or i - last_hedge[0] < 8:
+        if not hedging or i - last_hedge[0] < hedge_gap:
             return fut.result(), False
         if len(recent) < 3:
             # no history yet -- with several ranks a rank only searches the datasets it owns, so it may never have
@@ -811,6 +884,28 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             # the first search fills the pipeline (the first main pass waits for it): whole team; the others run
             # three (four) at a time and have as many device periods each
             th = fill_team if j == 0 else team  # (smaller teams for the searches right behind the first: slower, -1...3 %)
+            if use_service:
+                rec = hsearch["recs"][j % ring]
+                if j == slow_j:  # test hook: this search reaches the service late
+                    import threading
+
+                    hsearch["seq"][0] += 1
+                    seq = hsearch["seq"][0]
+                    rec[7] = 0
+
+                    def late(seq=seq, rec=rec, k=int(k), th=th):
+                        from . import _lib
+
+                        _lib.call("xm_hostsearch_submit", sel[j % ring].h_slice.data_ptr(), n, plan.extra["freq_c"].ctypes.data,
+                                  aps.METHODS.index(method), k, int(iw), int(bool(p0_only)), 42, 0.01, 1000, int(th), seq, rec.data_ptr())
+
+                    tm = threading.Timer(slow_ms * 1e-3, late)
+                    tm.daemon = True
+                    tm.start()
+                else:
+                    seq = submit_host_search(j, int(k), th, rec)
+                pending[j] = (res, ("host", seq), (sl, int(k), res.pivot))
+                return
             fut = (pool.submit(search, sl, int(k), res.pivot, th, ev, j) if pool is not None
                    else search(sl, int(k), res.pivot, th, ev))
         pending[j] = (res, fut, (sl, int(k), res.pivot))
@@ -886,6 +981,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 slot = bufs["sel_slots"][b]
                 gflat = (rank_offset_rows + int(slot[1].item()) // n) * n + k
                 res = AutophaseResult(0.0, 0.0, float(plan.freq[k]), int(gflat), int(k), float(slot[0].item()) ** 0.5)
+            res.p0, res.p1, res.nfev, res.fun, res.timing, res.hedged = p0, p1, nfev, fun, timing, hedged
+        elif isinstance(fut, tuple) and len(fut) == 2 and fut[0] == "host":  # a search on the library's native threads
+            p0, p1, nfev, fun, timing, hedged = collect_host(i, fut[1], search_args[1], ev)
             res.p0, res.p1, res.nfev, res.fun, res.timing, res.hedged = p0, p1, nfev, fun, timing, hedged
         elif fut is not None:
             if pool is not None:
