@@ -4,12 +4,16 @@
 One "step" = one full pass of  zero_fill -> apodize_exp -> to_spectrum -> autophase  over one
 synthetic batch that is already resident in HBM, run by the library's streaming executor
 `xmris_amd.pipeline.run_stream`.  Default (speculative) schedule, per step:
-    guess kernel (xm_row_l1: windowed L1 norm of every FID, streaming read) -> row with the largest norm
+    guess stage: coarse spectra of every row (`xm_guess_rows`: the first 512 windowed samples on a 1024-bin grid,
+    one wave per row) -> exact transform of every row whose estimate lies within a band of the largest
+    (`xm_guess_refine`, branch and bound; the last workgroup gathers the winning FID as complex128)
  -> that row's spectrum recomputed in complex128 (one workgroup, written to pinned host memory)
- -> host differential evolution (p0, p1) -> phase table (fp64 on the host, 64 KiB H2D)
- -> main kernel (fused zero-fill + window + FFT + fftshift + phase + per-row max |X|^2; reads the FIDs, writes
-    the spectra) -> device reduction of the TRUE global arg-max -> compared with the guess before the next main
-    pass is queued; a wrong guess is repaired exactly (never needed on this data; `speculation` in the JSON line)
+ -> the (p0, p1) search on it: scipy's differential evolution restated natively, on native host threads of the
+    library (`xm_hostsearch_submit`) or, where the host is short of cores, as one workgroup on a reserved CU
+    (`xm_search_launch`); the polish follows the reference's route wherever it iterates
+ -> main kernel (fused zero-fill + window + FFT + fftshift + phase ramp in closed form + global arg-max key; reads
+    the FIDs, writes the spectra) -> the TRUE global arg-max compared with the guess before the output buffer is
+    reused; a wrong guess is repaired exactly (`speculation`, `speculation_miss` in the JSON line)
 `--no-speculate`: the classic schedule -- an arg-max pre-pass (fused zero-fill + window + FFT + |X|^2 maxima,
 nothing written) finds the winning row before the search, the main kernel only writes.
 Over ranks: one O(1) exchange of (max, global flat index) per decision and one broadcast of (p0, p1).
@@ -25,7 +29,9 @@ with the worst child status; it refuses to run when fewer than N devices are vis
 Prints ONE JSON line on rank 0's stdout (see the driver contract; library chatter goes to stderr); `roofline`
 prices the dominant (main) kernel by HIP events on its stream, `cpu_baseline` times the CPU oracle.  The line
 carries its own footnotes, measured after the timed region (they never enter `value`): the classic schedule's
-rate, one dataset end to end without cross-dataset overlap, the cost of a wrong guess, a complex128 sub-record.
+rate, one dataset end to end without cross-dataset overlap, the cost of a wrong guess, a complex128 sub-record,
+BASELINE configs[1] and configs[4] end to end (`configs`), the README quick start against the oracle (`parity`);
+with --gpus N: `per_rank` (every rank's device period, search latency, searches owned).
 """
 import argparse
 import json
@@ -238,6 +244,10 @@ def main():
     local_rank %= max(1, n_dev)  # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if os.environ.get("XM_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after so many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["XM_BENCH_WATCHDOG"]), exit=True)
     if args.only_configs:
         os.write(result_fd, (json.dumps({"configs": configs_note(torch, pipeline, device, args)}) + "\n").encode())
         return
@@ -315,7 +325,7 @@ def main():
     # verification of step i then need not finish before step i+1's main pass is queued
     out = torch.empty((nv, N), dtype=cdtype, device=device)
     out_b = torch.empty((nv, N), dtype=cdtype, device=device)
-    times = {"pre_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": [], "gen_ms": [], "polish_ms": [], "table_ms": [], "period_ms": []}
+    times = {"pre_ms": [], "sel_ms": [], "main_ms": [], "solve_ms": [], "exchange_ms": [], "gen_ms": [], "polish_ms": [], "table_ms": [], "period_ms": []}
     last = {}
 
     plan = pipeline.make_plan(x, t, N, args.lb)
@@ -375,6 +385,8 @@ def main():
                 times["gen_ms"].append(r.timing.get("generations_ms", 0.0))
                 times["polish_ms"].append(r.timing.get("polish_ms", 0.0))
             times["pre_ms"].append(e["pre0"].elapsed_time(e["pre1"]))
+            if "sel1" in e:  # speculative schedule: exact check of the candidates + the winner's fp64 spectrum
+                times["sel_ms"].append(e["pre1"].elapsed_time(e["sel1"]))
             times["main_ms"].append(e["main0"].elapsed_time(e["main1"]))
             if i + 1 < n_steps:  # device-side period: start of main pass i -> start of main pass i+1
                 times["period_ms"].append(e["main0"].elapsed_time(trace[i + 1]["main0"]))
@@ -474,15 +486,13 @@ def main():
     pre_ms = float(np.mean(times["pre_ms"]))
     alg_bytes = (bytes_per * nt + bytes_per * N) * nv  # read each FID once + write each spectrum once
     achieved = alg_bytes / (main_ms * 1e-3) / 1e9
-    stream_ms = main_ms + pre_ms
-    hot = (nt, N) == (4096, 8192)
-    if args.dtype == "c64":
-        kernel = ("k_zf2p<FftPlan<4096,256,16,16,16>, " + ("13" if speculate else "9") + ", 11>" if hot
-                  else "xm_pipeline_fused_ramp main pass")
-    else:
-        kernel = ("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
-                  else "xm_pipeline_fused_ramp main pass")
-    kernel += " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
+    sel_ms = float(np.mean(times["sel_ms"])) if times["sel_ms"] else 0.0
+    stream_ms = main_ms + pre_ms + sel_ms  # every kernel of a step: guess (or pre-pass) + selection stage + main pass
+    # the kernels are named by the dispatcher that launched them (`xm_last_kernel_string`, read right behind the launch
+    # by the executor), not by this script
+    main_name = next((e["main_kernel"] for e in reversed(timed_trace) if e.get("main_kernel")), "xm_pipeline_fused_ramp main pass")
+    guess_name = next((e["guess_kernel"] for e in reversed(timed_trace) if e.get("guess_kernel")), None)
+    kernel = main_name + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
     traffic, traffic_source = pmc_traffic(args.dtype, kernel, nv, nt, N)
 
     result = {
@@ -511,7 +521,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
         },
         "breakdown_ms": {
-            ("guess_kernel_row_l1" if speculate else "prepass_kernel"): pre_ms, "main_kernel": main_ms,
+            ("guess_kernel" if speculate else "prepass_kernel"): pre_ms, "guess_kernel_name": guess_name,
+            "selection_stage_kernels": sel_ms if speculate else None,  # exact check of the candidates + the winner's fp64 spectrum
+            "main_kernel": main_ms,
             "selection_wait_and_exchange": float(np.mean(times["exchange_ms"])),
             # speculative schedule: searches run three datasets ahead on worker threads -- this is the LATENCY from a
             # dataset's exchange to the moment its (p0, p1) is consumed, not host time on the critical path
@@ -542,6 +554,16 @@ def main():
     }
     if world > 1:
         result["rccl_ranks"] = rccl_ranks  # None: the barrier / timing reduction ran on gloo (see stderr)
+        # how every rank's host kept up, in the line itself: a scaling record explains itself
+        mine_rec = {"rank": rank, "device_period_median_ms": float(np.median(times["period_ms"])) if times["period_ms"] else None,
+                    "search_latency_mean_ms": float(np.mean(times["solve_ms"])), "search_latency_max_ms": float(np.max(times["solve_ms"])),
+                    "searches_owned": len(times["gen_ms"]),
+                    "search_generations_mean_ms": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
+                    "main_kernel_ms": main_ms, "host_cores_used": cpu_cores, "ms_per_step_local": ms_per_step,
+                    "hedged": spec_stats.get("hedged", 0), "repaired": spec_stats.get("repaired", 0)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_rec, group=host_group)
+        result["per_rank"] = gathered
         # every rank reports how its host kept up (stderr): the search latency must stay below the look-ahead (two
         # device periods) or the searches pace the steps
         per = times["period_ms"]
@@ -565,6 +587,10 @@ def main():
             result["configs"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(x, t, N, args.lb, args.cpu_seconds, nv)
+        try:  # (same leg: the oracle as the checker)
+            result["parity"] = parity_note(torch, pipeline, dev, device)
+        except Exception as e:  # noqa: BLE001
+            result["parity"] = {"error": repr(e)[:200]}
         if cpu_pool is not None:
             try:
                 sample = x[:cpu_pool.shape[0]].to(torch.complex64).cpu().numpy()
@@ -769,10 +795,8 @@ def c128_note(torch, pipeline, xs, t, N, args, speculate):
     ms2 = (time.perf_counter() - t0) / k2 * 1e3
     main2 = float(np.mean([e["main0"].elapsed_time(e["main1"]) for e in trace]))
     bytes2 = 16 * (x2[0].shape[1] + N) * nv
-    hot = (x2[0].shape[1], N) == (4096, 8192)
-    kernel2 = (("k_zf2d<FftPlan<4096,256,16,16,16>, " + ("221" if speculate else "137") + ">" if hot
-                else "xm_pipeline_fused_ramp main pass")
-               + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")"))
+    main_name = next((e["main_kernel"] for e in reversed(trace) if e.get("main_kernel")), "xm_pipeline_fused_ramp main pass")
+    kernel2 = main_name + " (zero-fill+window+FFT+fftshift+phase" + ("+global arg-max)" if speculate else ")")
     traffic2, source2 = pmc_traffic("c128", kernel2, nv, x2[0].shape[1], N)
     return {"voxels": nv, "steps": k2, "value": nv / (ms2 * 1e-3), "ms_per_step": ms2, "dtype": "f64",
             "roofline": {"bound": "hbm", "kernel": kernel2,
@@ -783,6 +807,33 @@ def c128_note(torch, pipeline, xs, t, N, args, speculate):
             "end_to_end_roofline_frac": nv / (ms2 * 1e-3) * 16 * (x2[0].shape[1] + N) / 1e9 / HBM_PEAK_GBPS,
             "speculation": ({"hit": sum(r.speculation == "hit" for r in res),
                              "repaired": sum(r.speculation == "repaired" for r in res)} if speculate else None)}
+
+
+def parity_note(torch, pipeline, dev, device):
+    """BASELINE configs[0] (the README quick start: 5 x 1024 noise FIDs -> 2048, lb = 5, autophase) through the
+    STREAMING executor this script times, against the CPU oracle (part of the cpu_baseline leg: the oracle is the
+    checker).  north_star: <= 1e-5 of the spectrum's maximum.  On pure noise the landscape is flat; the search's
+    polish follows the reference's route wherever it iterates (polish="exact"), so what remains is the storage
+    precision of the slice the search sees (complex64: the 1e-7 of its samples moves the optimum by ~5e-4 degrees)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import xmris_oracle as orc
+
+    rng = np.random.default_rng(42)
+    t = np.linspace(0, 1, 1024)
+    x = rng.standard_normal((5, 1024)) + 1j * rng.standard_normal((5, 1024))
+    ref, info = orc.pipeline_values(x.astype(np.complex128), t, 2048, 5.0, peak_width=100)
+    out = {"workload": "BASELINE configs[0]: 5 x 1024 noise FIDs -> 2048, lb=5, autophase, via run_stream(speculate=True)",
+           "tolerance_north_star": 1e-5}
+    for name, dt in (("c1_c128", torch.complex128), ("c1_c64", torch.complex64)):
+        xd = torch.from_numpy(x).to(device=device, dtype=dt)
+        plan = pipeline.make_plan(xd, t, 2048, 5.0)
+        outs = [torch.empty((5, 2048), dtype=dt, device=device) for _ in range(6)]
+        res = pipeline.run_stream([xd] * 6, outs, plan, speculate=True)
+        err = max(float(np.abs(o.cpu().numpy() - ref).max() / np.abs(ref).max()) for o in outs)
+        out[name] = {"spectrum_rel_err": err, "dp0_deg": abs(res[-1].p0 - info["p0"]), "dp1_deg": abs(res[-1].p1 - info["p1"]),
+                     "flat_index_equal": bool(res[-1].flat_index == info["flat_idx"]), "nfev": int(res[-1].nfev),
+                     "nfev_oracle": int(info["nfev"])}
+    return out
 
 
 def cpu_baseline(x, t, N, lb, budget_s, nv_full):

@@ -70,6 +70,10 @@ typedef struct {
 int xm_version(void); /* 10000*major + 100*minor + patch */
 const char* xm_last_error_string(void);
 int xm_clear_cache(void);
+/* The kernel the fused dispatcher (xm_pipeline_fused / _ramp, xm_fft1d_batched, xm_guess_*) launched last ON THE
+ * CALLING THREAD, spelled as the profiler spells it, e.g. "k_zf2p<FftPlan<4096,256,16,16,16>, 13, 11>" (template, plan,
+ * mode words): reports and counter files are matched against this, not against a string typed by hand. */
+const char* xm_last_kernel_string(void);
 /* 1 if a length-n transform of `dtype` has an in-LDS plan (direct or Bluestein), else 0. */
 int xm_fft_supported(int n, int dtype);
 /* Build (and cache) the tables for length n so that later calls do no allocation. */

@@ -207,6 +207,7 @@ def install(monkeypatch=None):
                  "new_argmax_key", "new_key_result", "read_key_result", "new_search_record", "search_supported",
                  "search_launch", "search_done"):
         put(device, name, globals()[name])
+    put(device, "last_kernel", lambda: "numpy double")
     put(device, "key_native", lambda *a, **k: True)
     put(device, "guess_supported", lambda *a, **k: True)
     put(device, "ramp_native", lambda *a, **k: True)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "xm_version": (_i, []),
     "xm_last_error_string": (ctypes.c_char_p, []),
     "xm_clear_cache": (_i, []),
+    "xm_last_kernel_string": (ctypes.c_char_p, []),
     "xm_fft_supported": (_i, [_i, _i]),
     "xm_plan_prepare": (_i, [_i, _i]),
     "xm_zero_fill": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),

@@ -18,6 +18,28 @@
 #define XM_VERSION_NUM 301  // 0.3.1 (round 3: xm_guess_*, xm_pipeline_key_native, XM_KEY_BYTES 131072; xm_solver_fg, xm_solver_pool_backups)
 
 static thread_local std::string g_err;
+static thread_local std::string g_last_kernel;
+
+#include <cxxabi.h>
+void xm_note_kernel(const char* base, const std::type_info* plan, const char* scalar, int mode, int opt) {
+  std::string name = base;
+  name += "<";
+  if (scalar) name += std::string(scalar) + ", ";
+  if (plan) {
+    int status = 0;
+    char* dm = abi::__cxa_demangle(plan->name(), nullptr, nullptr, &status);
+    std::string pn = (status == 0 && dm) ? dm : plan->name();
+    if (dm) free(dm);
+    std::string packed;  // "FftPlan<4096, 256, 16, 16, 16>" -> "FftPlan<4096,256,16,16,16>" (the spelling of the reports)
+    for (size_t i = 0; i < pn.size(); ++i)
+      if (!(pn[i] == ' ' && i > 0 && pn[i - 1] == ',')) packed += pn[i];
+    name += packed + ", ";
+  }
+  name += std::to_string(mode);
+  if (opt >= 0) name += ", " + std::to_string(opt);
+  name += ">";
+  g_last_kernel = name;
+}
 int xm_fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -341,6 +363,8 @@ extern "C" int xm_stream_cus(void* stream) {
   const int rc = xm_stream_cu_count((hipStream_t)stream, &cus);
   return rc ? rc : cus;
 }
+
+const char* xm_last_kernel_string(void) { return g_last_kernel.c_str(); }
 
 int xm_clear_cache(void) {
   {

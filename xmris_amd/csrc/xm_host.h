@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <typeinfo>
 #include <vector>
 
 int xm_fail(int code, const std::string& msg);
@@ -101,3 +102,8 @@ int xm_resident_blocks(XmResidency& r, K kern, int nt, size_t lds, int* out, hip
   *out = per_cu * cus;
   return XM_OK;
 }
+
+// What the dispatcher launched last on this thread, as the profiler names it (`xm_last_kernel_string`): the fused
+// launchers note the kernel template, its plan and its mode words right before the launch -- reports quote this
+// instead of a string typed by hand.
+void xm_note_kernel(const char* base, const std::type_info* plan, const char* scalar, int mode, int opt);

@@ -62,6 +62,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
     rc = xm_queue_slot(&A.queue);
     if (rc) return rc;
   }
+  xm_note_kernel("k_zf2p", &typeid(PL), nullptr, MODE, OPT);
   hipLaunchKernelGGL((k_zf2p<PL, MODE, OPT>), dim3((unsigned)blocks), dim3(PL::NT), lds, st, A);
   HIP_TRY(hipGetLastError());
   return XM_OK;

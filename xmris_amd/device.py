@@ -547,6 +547,12 @@ def gather_row_c128(x2, gflat, n_per_row: int, out=None):
     return out
 
 
+def last_kernel() -> str:
+    """`xm_last_kernel_string`: the kernel the fused dispatcher launched last on this thread, as the profiler names it."""
+    v = _lib.load().xm_last_kernel_string()
+    return v.decode("utf-8", "replace") if v else ""
+
+
 def fft_supported(n: int, complex128: bool = False) -> bool:
     if n == 1:
         return True

@@ -655,8 +655,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         hsearch = plan.extra.get(("host_search", ring))
         if hsearch is None:
             hsearch = plan.extra[("host_search", ring)] = dict(
-                recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)],
-                spare=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(2)], seq=[0])
+                recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)], seq=[0], retired=[])
         if plan.extra.get("freq_c") is None:
             plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
 
@@ -687,17 +686,27 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         deadline = ev["t_exchanged"] + 2.0 * typical + 0.5e-3
         can_hedge = hedging and i - last_hedge[0] >= hedge_gap
         second, hedged, nap = None, False, 0.0
+        give_up = time.perf_counter() + 120.0
         while True:
             if dev.search_done(rec, seq):
                 break
             if second is not None and dev.search_done(second[0], second[1]):
+                # the first submission is still on its way: it will write its record whenever it ends, so that record
+                # leaves the ring (a later dataset's result in the same slot must not be overwritten by it)
+                hsearch["retired"].append(rec)
+                del hsearch["retired"][:-64]
+                hsearch["recs"][b] = torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64)
                 rec = second[0]
                 break
-            if can_hedge and second is None and time.perf_counter() > deadline:
+            now = time.perf_counter()
+            if can_hedge and second is None and now > deadline:
                 last_hedge[0] = i
-                spare = hsearch["spare"][i & 1]
+                spare = torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64)  # (its own record: see above)
+                hsearch["retired"].append(spare)
                 second = (spare, submit_host_search(i, k, fill_team, spare))
                 hedged = True
+            if now > give_up:
+                raise RuntimeError("the search service did not answer within two minutes")
             if blocking:
                 nap = min(1e-4, nap + 1e-5)
                 time.sleep(nap)
@@ -730,10 +739,14 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                        key=bufs["gkey"][b] if l1_keys else None)
         if trace is not None:
             ev["pre1"].record()
+            ev["guess_kernel"] = dev.last_kernel()
         sel[b] = Selection(inputs[j], plan, bufs["norm"][b], bufs["zero_idx"], index_from_slice=True,
                            key=bufs["gkey"][b] if l1_keys else None, slot=bufs["sel_slots"][b],
                            refine=(plan.extra["window32"], bufs["est"][b], bufs["gkey"][b], bufs["wkey"], band)
                            if use_guess else None, blocking=blocking)
+        if trace is not None:  # (the selection stage: exact check of the candidates + the winner's fp64 spectrum)
+            ev["sel1"] = torch.cuda.Event(enable_timing=True)
+            ev["sel1"].record()
         if use_dev and exchange is None and j >= cpu_fill:
             # one rank: the winner needs no exchange -- the search kernel is queued at once, gated on the selection
             # stage by an event; this thread does not wait for either
@@ -771,7 +784,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         rec = dsearch["recs"][b]
         deadline = time.perf_counter() + max(4.0 * est_ms * 1e-3, 8e-3)
         nap = 0.0
-        while not dev.search_done(rec, seq):
+        while not dev.search_done(rec, seq):  # (bounded: past the deadline the host engine takes over)
             if time.perf_counter() > deadline:
                 sl = sel[b].h_slice[0].numpy().copy()
                 k = int(np.argmax(np.abs(sl)))
@@ -1016,6 +1029,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                       argidx=bufs["tidx"][b], argmax_value_only=True)
         if trace is not None:
             ev["main1"].record()
+            ev["main_kernel"] = dev.last_kernel()
         if not use_keys:
             dev.argmax_reduce_async(bufs["tmax"][b], bufs["tidx"][b], n, gmax=bufs["vmax"][b], gflat=bufs["vflat"][b])
         ev["verify_event"] = torch.cuda.Event(blocking=blocking)
