@@ -359,6 +359,26 @@ def test_xarray_bridge_through_a_test_double(oracle, monkeypatch):
         np.testing.assert_array_equal(got.coords[k].values, c.values)
         assert got.coords[k].attrs == c.attrs and got.coords[k].dims == (c.dim,)
     assert da.attrs == {"B0": 3.0} and da.values is not got.values  # the input is untouched
+    # SURVEY 8f rank 2 on the reference's own container: every step of the chain came back as a DataArray around a
+    # duck array (xarray's protocol: `is_duck_array`) that is still a RECORDED step -- shape / dtype / coords / attrs
+    # known, nothing computed -- and `.values` / numpy functions / arithmetic compute it
+    z = da.xmr.zero_fill(target_points=128)
+    assert isinstance(z, xr.DataArray) and isinstance(z.data, labeled.LazyDuck) and xr.is_duck_array(z.data)
+    assert z.data.node.is_deferred and z.shape == (3, 128) and z.dtype == np.complex128 and z.attrs["zero_fill_target"] == 128
+    a2 = z.xmr.apodize_exp(lb=5.0)
+    assert isinstance(a2.data, labeled.LazyDuck) and a2.data.node.is_deferred
+    steps, chain_root = a2.data.node.pending_chain()
+    assert [s_[0] for s_ in steps] == ["apodize_exp", "zero_fill"] and not chain_root.is_deferred  # ONE chain across the DataArrays
+    assert z.data.node.is_deferred  # ... and asking for the later step did not compute the earlier one's DataArray
+    np.testing.assert_allclose(np.abs(a2.data).max(), np.abs(oracle.apodize_exp(oracle.zero_fill(
+        oracle.Labeled(x, ("voxel", "time"), {"time": oracle.Coord("time", t)}), target_points=128), lb=5.0).values).max(), rtol=1e-12)
+    assert np.asarray(z.data).shape == (3, 128) and (z.data + 0).dtype == np.complex128 and z.data[0, :4].shape == (4,)
+    # an edit on an intermediate DataArray is honoured by the next call (the chain takes the DataArray's metadata)
+    z.attrs["note"] = "edited"
+    assert z.xmr.apodize_exp(lb=5.0).attrs["note"] == "edited"
+    monkeypatch.setenv("XMRIS_AMD_XARRAY_EAGER", "1")
+    assert isinstance(da.xmr.zero_fill(target_points=128).data, np.ndarray)
+    monkeypatch.delenv("XMRIS_AMD_XARRAY_EAGER")
     # functions take DataArrays too, and hand back the caller's container type
     assert isinstance(xm.to_spectrum(da), xr.DataArray)
     assert isinstance(xm.to_spectrum(labeled.as_labeled(da)), xm.LabeledArray)

@@ -392,3 +392,51 @@ def test_chain_that_stops_before_the_fft_is_one_launch(xm, oracle, monkeypatch, 
         assert zf.is_deferred  # the zero-filled intermediate was never materialised
         assert vals.dtype == np.complex128 and np.array_equal(vals.view(np.uint8), np.asarray(ref.values).view(np.uint8))
         _same(ap, ref, 1e-300)
+
+
+def test_dataarray_chain_is_fused_like_the_labeled_one(xm, oracle, monkeypatch):
+    """SURVEY 8f rank 2 for the reference's REAL container (accessor.py:452-550, 630-683; README.md:66-73): the four
+    `.xmr` calls on (a test double of) `xarray.DataArray` hand DataArrays back whose data are recorded steps behind
+    xarray's duck-array protocol, `autophase` runs the fused kernels on the root -- two launches over the data, none of
+    the staged zero-fill / apodise / FFT kernels, no intermediate -- and the result is a numpy-backed DataArray with the
+    oracle's dims, coords, attrs and values."""
+    import _fake_xarray
+
+    from xmris_amd import accessor, labeled
+    from xmris_amd import device as dev
+
+    xr = _fake_xarray.install(monkeypatch)
+    accessor.register_xarray_accessor(force=True)
+    nv, nt = 24, 1024
+    rng = np.random.default_rng(12)
+    t = np.arange(nt) * 2e-4
+    amp = 0.5 + rng.random(nv)
+    amp[7] = 3.0
+    x = (amp[:, None] * (np.exp(-25 * t) * np.exp(2j * np.pi * 410 * t) + 0.4 * np.exp(-35 * t) * np.exp(-2j * np.pi * 900 * t))[None, :]
+         + 0.02 * (rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt))))
+    da = xr.DataArray(x, dims=("voxel", "time"), coords={"voxel": np.arange(nv), "time": t}, attrs={"MHz": 120.0})
+    o = oracle.Labeled(x, ("voxel", "time"), {"voxel": oracle.Coord("voxel", np.arange(nv)), "time": oracle.Coord("time", t)}, {"MHz": 120.0})
+    calls = {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 0}
+    for name in calls:
+        real = getattr(dev, name)
+        monkeypatch.setattr(dev, name, (lambda real, name: lambda *a_, **k_: (calls.__setitem__(name, calls[name] + 1), real(*a_, **k_))[1])(real, name))
+    zf = da.xmr.zero_fill(target_points=2048)
+    ap = zf.xmr.apodize_exp(lb=5.0)
+    sp = ap.xmr.to_spectrum()
+    for step in (zf, ap, sp):
+        assert isinstance(step, xr.DataArray) and isinstance(step.data, labeled.LazyDuck) and step.data.node.is_deferred
+    assert sp.shape == (nv, 2048) and sp.dims == ("voxel", "frequency") and calls == {"zero_fill": 0, "apodize": 0, "fft": 0, "pipeline_fused": 0}
+    got = sp.xmr.autophase()
+    assert isinstance(got, xr.DataArray) and isinstance(got.data, np.ndarray)
+    assert (calls["zero_fill"], calls["apodize"], calls["fft"]) == (0, 0, 0), calls  # none of the staged kernels ran
+    assert zf.data.node.is_deferred and sp.data.node.is_deferred                      # ... and no intermediate exists
+    oc = oracle.autophase(oracle.to_spectrum(oracle.apodize_exp(oracle.zero_fill(o, target_points=2048), lb=5.0)), peak_width=100)
+    assert got.dims == oc.dims and got.attrs.keys() == oc.attrs.keys()
+    assert abs(got.attrs["phase_p0"] - oc.attrs["phase_p0"]) < 1e-6 and abs(got.attrs["phase_p1"] - oc.attrs["phase_p1"]) < 1e-6
+    assert np.abs(got.values - oc.values).max() / np.abs(oc.values).max() < 1e-9
+    for k, c in oc.coords.items():
+        np.testing.assert_array_equal(got.coords[k].values, c.values)
+    # looking at an intermediate computes it (one fused launch for zero fill + window), the rest of the chain still works
+    v = np.asarray(ap.data)
+    assert v.shape == (nv, 2048) and not ap.data.node.is_deferred
+    assert np.abs(sp.xmr.autophase().values - oc.values).max() / np.abs(oc.values).max() < 1e-9

@@ -270,12 +270,14 @@ static int launch_zf_apod(const void* in, int64_t in_stride, void* out, const vo
     rc = xm_resident_blocks(res, k_zf_apod<TI, TO, true>, 256, lds, &resident, st);
     if (rc) return rc;
     const long long blocks = n_batch < resident ? n_batch : resident;
+    xm_note_kernel("k_zf_apod", nullptr, sizeof(TI) == 4 ? (sizeof(TO) == 4 ? "float, float" : "float, double") : "double, double", 1, -1);
     hipLaunchKernelGGL((k_zf_apod<TI, TO, true>), dim3((unsigned)blocks), dim3(256), lds, st, A);
   } else {
     static XmResidency res;
     rc = xm_resident_blocks(res, k_zf_apod<TI, TO, false>, 256, lds, &resident, st);
     if (rc) return rc;
     const long long blocks = n_batch < resident ? n_batch : resident;
+    xm_note_kernel("k_zf_apod", nullptr, sizeof(TI) == 4 ? (sizeof(TO) == 4 ? "float, float" : "float, double") : "double, double", 0, -1);
     hipLaunchKernelGGL((k_zf_apod<TI, TO, false>), dim3((unsigned)blocks), dim3(256), lds, st, A);
   }
   HIP_TRY(hipGetLastError());

@@ -25,6 +25,38 @@ struct ZfApodArgs {
   int n_in, n_out, pad_left;
 };
 
+template <class TI, int EPL>
+XM_DEV void load_vec(const Cx<TI>* p, Cx<TI> (&v)[EPL]) {  // 16 bytes, nontemporal: the FIDs are read once
+  if constexpr (sizeof(Cx<TI>) == 8) {
+    const xm_f4 q = __builtin_nontemporal_load(reinterpret_cast<const xm_f4*>(p));
+    v[0] = mk<TI>(q.x, q.y);
+    v[1] = mk<TI>(q.z, q.w);
+  } else {
+    const xm_d2 q = __builtin_nontemporal_load(reinterpret_cast<const xm_d2*>(p));
+    v[0] = mk<TI>(q.x, q.y);
+  }
+}
+template <class TO, int EPL>
+XM_DEV void store_vec(Cx<TO>* p, const Cx<TO> (&y)[EPL]) {  // 16-byte nontemporal stores
+  if constexpr (sizeof(Cx<TO>) == 8) {
+    static_assert(EPL == 2, "two complex64 per 16 bytes");
+    xm_f4 q;
+    q.x = (float)y[0].re;
+    q.y = (float)y[0].im;
+    q.z = (float)y[1].re;
+    q.w = (float)y[1].im;
+    __builtin_nontemporal_store(q, reinterpret_cast<xm_f4*>(p));
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      xm_d2 q;
+      q.x = (double)y[e].re;
+      q.y = (double)y[e].im;
+      __builtin_nontemporal_store(q, reinterpret_cast<xm_d2*>(p + e));
+    }
+  }
+}
+
 // VEC: every row of the input and the output is 16-byte aligned and pad_left / n_in are even for 8-byte elements, so a
 // lane moves 16 bytes of input per step.  Otherwise: one element per lane and step (any geometry).
 template <class TI, class TO, bool VEC>
@@ -47,56 +79,57 @@ __global__ __launch_bounds__(256) void k_zf_apod(ZfApodArgs<TI, TO> A) {
     if (t == 0) ticket[(it + 1) & 1] = (long long)gridDim.x + (long long)atomicAdd(A.queue, 1u);
     const Cx<TI>* __restrict__ irow = A.in + row * A.in_stride;
     Cx<TO>* __restrict__ orow = A.out + row * (long long)A.n_out;
-    for (int j0 = t * EPL; j0 < A.n_out; j0 += per_step) {
+    auto one_step = [&](int j0) {
       const int k = j0 - A.pad_left;  // input index of the first element
       Cx<TO> y[EPL];
-      if (k >= 0 && k + EPL <= A.n_in) {
-        Cx<TI> v[EPL];
-        if constexpr (VEC && EPL == 2) {
-          const xm_f4 q = __builtin_nontemporal_load(reinterpret_cast<const xm_f4*>(irow + k));
-          v[0] = mk<TI>(q.x, q.y);
-          v[1] = mk<TI>(q.z, q.w);
-        } else if constexpr (VEC) {
-          const xm_d2 q = __builtin_nontemporal_load(reinterpret_cast<const xm_d2*>(irow + k));
-          v[0] = mk<TI>(q.x, q.y);
-        } else {
-          v[0] = irow[k];
-        }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const TO w = wl[j0 + e];
-          y[e] = mk<TO>((TO)v[e].re * w, (TO)v[e].im * w);  // complex times real: two products, as numpy's
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int ke = k + e;
-          const bool in_range = ke >= 0 && ke < A.n_in && j0 + e < A.n_out;
-          const Cx<TI> v = in_range ? irow[ke] : mk<TI>(TI(0), TI(0));
-          const TO w = in_range ? wl[j0 + e] : TO(0);
-          y[e] = mk<TO>((TO)v.re * w, (TO)v.im * w);
-          if (!in_range) y[e] = mk<TO>(TO(0), TO(0));  // the padding is +0, whatever the window holds there
-        }
+      for (int e = 0; e < EPL; ++e) {
+        const int ke = k + e;
+        const bool in_range = ke >= 0 && ke < A.n_in && j0 + e < A.n_out;
+        const Cx<TI> v = in_range ? irow[ke] : mk<TI>(TI(0), TI(0));
+        const TO w = in_range ? wl[j0 + e] : TO(0);
+        y[e] = in_range ? mk<TO>((TO)v.re * w, (TO)v.im * w) : mk<TO>(TO(0), TO(0));  // the padding is +0
       }
-      if constexpr (VEC && sizeof(Cx<TO>) == 8) {  // two complex64 results: one 16-byte store
-        xm_f4 q;
-        q.x = (float)y[0].re;
-        q.y = (float)y[0].im;
-        q.z = (float)y[1].re;
-        q.w = (float)y[1].im;
-        __builtin_nontemporal_store(q, reinterpret_cast<xm_f4*>(orow + j0));
-      } else if constexpr (VEC) {  // complex128 results: a 16-byte store each
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          xm_d2 q;
-          q.x = (double)y[e].re;
-          q.y = (double)y[e].im;
-          __builtin_nontemporal_store(q, reinterpret_cast<xm_d2*>(orow + j0 + e));
-        }
+      if constexpr (VEC) {
+        store_vec(orow + j0, y);
       } else {
         if (j0 < A.n_out) orow[j0] = y[0];
       }
+    };
+    int j0 = t * EPL;
+    if constexpr (VEC) {
+      // four steps at a time wherever all of them lie inside the acquired samples (four 16-byte loads in flight per
+      // lane, then the products, then the stores) or inside the padding (stores only)
+      constexpr int U = 4;
+      for (; j0 + (U - 1) * per_step + EPL <= A.n_out; j0 += U * per_step) {
+        const int k = j0 - A.pad_left;
+        if (k >= 0 && k + (U - 1) * per_step + EPL <= A.n_in) {
+          Cx<TI> v[U][EPL];
+#pragma unroll
+          for (int u = 0; u < U; ++u) load_vec(irow + k + u * per_step, v[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            Cx<TO> y[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const TO w = wl[j0 + u * per_step + e];
+              y[e] = mk<TO>((TO)v[u][e].re * w, (TO)v[u][e].im * w);  // complex times real: two products, as numpy's
+            }
+            store_vec(orow + j0 + u * per_step, y);
+          }
+        } else if (k >= A.n_in || k + (U - 1) * per_step + EPL <= 0) {
+          Cx<TO> z[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) z[e] = mk<TO>(TO(0), TO(0));
+#pragma unroll
+          for (int u = 0; u < U; ++u) store_vec(orow + j0 + u * per_step, z);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) one_step(j0 + u * per_step);
+        }
+      }
     }
+    for (; j0 < A.n_out; j0 += per_step) one_step(j0);
     __syncthreads();
     row = nxt;
   }

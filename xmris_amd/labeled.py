@@ -214,6 +214,8 @@ class LabeledArray:
     # ---- xarray bridge ------------------------------------------------------------------------
     @classmethod
     def from_xarray(cls, da):
+        duck = getattr(da, "data", None)
+        lazy_node = duck.node if isinstance(duck, LazyDuck) else None
         coords = {}
         for k, c in da.coords.items():
             if c.ndim == 1:
@@ -224,13 +226,30 @@ class LabeledArray:
                 raise NotImplementedError(f"coordinate {k!r} spans {c.ndim} dimensions {tuple(c.dims)}: xmris_amd carries "
                                           f"one-dimensional coordinates only (drop or reset it before the call)")
             # 0-d (scalar) coordinates carry no axis information for this path and are not kept
+        if lazy_node is not None:
+            # The DataArray wraps a step of a recorded chain (`to_xarray(lazy=True)`): the chain goes on -- with the
+            # DataArray's CURRENT dims / coords / attrs / name, so an edit the caller made on it is seen by whoever
+            # replays the chain's metadata (phasing._chain_metadata_untouched) -- and with the node's data once
+            # somebody has computed them.
+            data = lazy_node._lazy if lazy_node._data is None else lazy_node._data
+            if tuple(da.dims) == lazy_node.dims:
+                return cls(data, da.dims, coords, dict(da.attrs), da.name)
         return cls(np.asarray(da.values), da.dims, coords, dict(da.attrs), da.name)
 
-    def to_xarray(self):
+    def to_xarray(self, lazy: bool = False):
+        """An `xarray.DataArray` with this array's dims / coords / attrs / name.  Its data are host values (the
+        reference's contract: numpy-backed, `accessor.py:452-550`) -- or, with `lazy` and while this array is still a
+        recorded step, a `LazyDuck` around it: shape, dtype, coordinates and attrs are there at once, the next `.xmr`
+        call continues the recorded chain, and `.values` / `np.asarray` / any arithmetic computes."""
         import xarray as xr
 
         coords = {k: xr.Variable(c.dim, c.values, attrs=dict(c.attrs)) for k, c in self.coords.items()
                   if c.dim in self.dims}
+        if lazy and self.is_deferred:
+            try:
+                return xr.DataArray(LazyDuck(self), dims=self.dims, coords=coords, attrs=dict(self.attrs), name=self.name)
+            except Exception:  # noqa: BLE001 -- an xarray that refuses the duck array gets host values
+                pass
         return xr.DataArray(self.values, dims=self.dims, coords=coords, attrs=dict(self.attrs), name=self.name)
 
 
@@ -247,5 +266,70 @@ def as_labeled(obj) -> LabeledArray:
 
 
 def like_input(result: LabeledArray, original):
-    """Return the result in the caller's container type (xarray in -> xarray out, on the host)."""
-    return result.to_xarray() if is_xarray(original) else result
+    """Return the result in the caller's container type: xarray in -> xarray out.  A result that is still a recorded
+    step (zero_fill / apodize_* / to_spectrum with the lazy chain on) goes back as a DataArray around a `LazyDuck`, so
+    the reference's four-call chain on DataArrays (README.md:66-73) fuses exactly like it does on LabeledArrays;
+    everything else goes back with host values, as the reference's contract has it."""
+    if not is_xarray(original):
+        return result
+    import os
+
+    lazy = result.is_deferred and not os.environ.get("XMRIS_AMD_EAGER") and not os.environ.get("XMRIS_AMD_XARRAY_EAGER")
+    return result.to_xarray(lazy=lazy)
+
+
+class LazyDuck(np.lib.mixins.NDArrayOperatorsMixin):
+    """A duck array in xarray's sense (`shape`, `dtype`, `ndim`, `__array__`, `__array_ufunc__`, `__array_function__`:
+    xarray's documented requirements, "Working with numpy-like arrays") around ONE recorded step of the `.xmr` chain
+    (`node`, a deferred `LabeledArray`).  Nothing is computed to make it or to carry it through `xr.DataArray(...)`;
+    `np.asarray(duck)` -- what `DataArray.values` does -- any numpy function, any arithmetic, indexing or `astype`
+    computes the node's data (on the GPU, fused where the chain allows, `processing/_common.fused_materialise`) and
+    continues on the host ndarray, as the reference's numpy-backed DataArrays would (the arithmetic operators come
+    from numpy's `NDArrayOperatorsMixin`, i.e. through `__array_ufunc__`)."""
+
+    __slots__ = ("node",)
+
+    def __init__(self, node: LabeledArray):
+        self.node = node
+
+    shape = property(lambda self: tuple(self.node.shape))
+    dtype = property(lambda self: np.dtype(self.node.dtype))
+    ndim = property(lambda self: len(self.node.shape))
+    size = property(lambda self: int(np.prod(self.node.shape, dtype=np.int64)))
+    nbytes = property(lambda self: self.size * np.dtype(self.node.dtype).itemsize)
+
+    def __len__(self):
+        if not self.node.shape:
+            raise TypeError("len() of unsized object")
+        return self.node.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.node.values, dtype=dtype)
+
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+
+    def astype(self, dtype, **kw):
+        return np.asarray(self).astype(dtype, **kw)
+
+    def copy(self):
+        return np.array(self)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        args = [np.asarray(x) if isinstance(x, LazyDuck) else x for x in inputs]
+        if "out" in kwargs:
+            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, LazyDuck) else o for o in kwargs["out"])
+        return getattr(ufunc, method)(*args, **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        def plain(x):
+            if isinstance(x, LazyDuck):
+                return np.asarray(x)
+            if isinstance(x, (list, tuple)):
+                return type(x)(plain(v) for v in x)
+            return x
+
+        return func(*plain(args), **{k: plain(v) for k, v in kwargs.items()})
+
+    def __repr__(self):
+        return f"<xmris_amd.LazyDuck {self.shape} {self.dtype}: recorded {self.node._lazy.step[0] if self.node.is_deferred else 'step (computed)'}>"
