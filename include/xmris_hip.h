@@ -63,7 +63,9 @@ typedef struct {
   float pad_;
   int64_t flat; /* winning row * n_out (index along the axis: 0) */
 } xm_argmax_result;
-/* XM_C128 takes XM_AMAX_GLOBAL_KEY on the geometries of xm_pipeline_key_native (half lengths 4096 and 8192) and only with a
+/* XM_C64 without a >= 2x zero fill (the plans of k_fft2: 512 ... 8192, 3 * 2^k) takes the key in the
+ * xm_pipeline_fused_ramp form only, with an output and at least two rows.
+ * XM_C128 takes XM_AMAX_GLOBAL_KEY on the geometries of xm_pipeline_key_native (half lengths 4096 and 8192) and only with a
  * result record: 64 bits of value + a row do not fit one atomic, so every wave leaves its (value, row) pair in a slot
  * of the key buffer and the last workgroup out merges them; the key buffer needs no clearing. */
 

@@ -731,8 +731,8 @@ def test_solver_team_budget(monkeypatch):
     # periods), half of it when the host paces the steps (every team spins all the time)
     from xmris_amd import pipeline as pipe
 
-    assert (aps.stream_threads(), aps.stream_threads(host_paced=True)) == (12, 8)
-    assert (pipe._search_team(2), pipe._search_team(3), pipe._search_team(4)) == (6, 4, 2)
+    assert (aps.stream_threads(), aps.stream_threads(host_paced=True)) == (12, 16)
+    assert (pipe._search_team(2), pipe._search_team(3), pipe._search_team(4)) == (6, 4, 4)
     share["n"] = 6
     assert (aps.default_threads(), aps.burst_threads()) == (2, 4)
     share["n"] = 256

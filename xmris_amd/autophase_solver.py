@@ -175,13 +175,19 @@ def stream_threads(host_paced: bool = False) -> int:
     threads each (`pipeline._search_workers`: the same throughput again, a third device period of slack for a search
     that runs late).  The WHOLE share (two teams of eight, 1.05 ms) is 2 % faster when nothing goes wrong and stalled
     for 2-5 ms in three of seven runs: sixteen spinning threads plus the launch thread oversubscribe a 16-CPU quota.
-    `host_paced` (more than three searches in flight: every team spins all the time): half of the share -- with four
-    teams of three BASELINE configs[1] 16,384 x 2048 -> 4096 lost 10 %.  Several ranks on one node, or XM_SOLVER_THREADS: `default_threads`."""
+    `host_paced` (more than three searches in flight: every team spins all the time): the whole share (see below; round
+    3, with the searches on Python threads: half).  Several ranks on one node, or XM_SOLVER_THREADS: `default_threads`."""
     import os
 
-    if host_paced or os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
+    if os.environ.get("XM_SOLVER_THREADS") or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
         return default_threads()
     cpus = min(16, _cpu_share())
+    if host_paced:
+        # Round 4: the searches run on native threads of the library now (`xm_hostsearch_submit`), no interpreter lock
+        # is fought over, and where the searches pace the steps the WHOLE share is theirs -- 16,384 x 2048 -> 4096 with
+        # four searches in flight: 0.38 ms per dataset with teams of two (round 3's half share), 0.31 with three,
+        # 0.26 with four (profiles/r04/search_workers.txt).
+        return max(default_threads(), cpus)
     return max(default_threads(), cpus - cpus // 4)
 
 

@@ -712,6 +712,12 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
   // comes from the kernel arguments -- no table, no per-output load (forward transforms only)
   constexpr bool RAMP = (MODE & ZF2_RAMP) != 0;
   static_assert(!(PHASE && RAMP) && (!RAMP || (WRITE && P <= 16)), "a ramp replaces the table of a writing mode; 16 slots");
+  // ZF2_GKEY (round 4): the launch's global arg-max goes into the arg-max key (PipeArgs::gkey, as in k_zf2p) instead
+  // of per-row arrays -- every wave keeps the best (max |X|^2 bits, row) of the row PARTS it transforms, merges it with
+  // one atomic when it leaves, the last workgroup out decodes the key into the caller's record: no index scan, no
+  // per-row reduction through the LDS, no barrier, and no reduction launches behind the kernel.
+  constexpr bool GKEY = (MODE & ZF2_GKEY) != 0;
+  static_assert(!GKEY || AMAX, "the key holds maxima");
   using FFT = BlockFFT<V, PL>;
   using HT = HotTw<T, PL, RAMP>;
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
@@ -763,6 +769,8 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
   };
   long long g = blockIdx.x;
   if (g < npairs) fetch(g, t, A.in_shift, A.pad_left, last_in);
+  unsigned best_key = 0u, best_row = 0u;  // GKEY: this wave's best so far (wave-uniform)
+  bool have = false;
 
   for (; g < npairs; g += gridDim.x) {
     int tt = t, osh = A.out_shift, ish = A.in_shift, padl = A.pad_left;
@@ -795,6 +803,21 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
       }
       b0 = amax_nan_if_unset(b0);
       b1 = amax_nan_if_unset(b1);
+      if constexpr (GKEY) {
+        // rows come in ascending order: strict > keeps the lowest row among equal values; a NaN (bit pattern above every
+        // number) outranks everything, as np.argmax has it
+        const unsigned k0 = wave_reduce_u32<true>(b0 != b0 ? 0x7fc00000u : __float_as_uint(b0));
+        const unsigned k1 = wave_reduce_u32<true>(b1 != b1 ? 0x7fc00000u : __float_as_uint(b1));
+        if (!have || k0 > best_key) {
+          best_key = k0;
+          best_row = (unsigned)s0;
+          have = true;
+        }
+        if (has1 && k1 > best_key) {
+          best_key = k1;
+          best_row = (unsigned)s1;
+        }
+      } else {
       const bool nan0 = b0 != b0, nan1 = b1 != b1;
       int i0 = 0x7fffffff, i1 = 0x7fffffff;
 #pragma unroll
@@ -808,6 +831,7 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
       amax_reduce_store<T, NT>(b0, i0, tt, true, s0, A.absmax2, A.argidx, red_v, red_i);
       amax_reduce_store<T, NT>(b1, i1, tt, has1, has1 ? s1 : s0, A.absmax2, A.argidx, red_v + NT / XM_WAVE + 1,
                                red_i + NT / XM_WAVE + 1);
+      }
     }
     if constexpr (WRITE) {
       Cx<T>* __restrict__ o0 = A.out + s0 * (long long)N;
@@ -825,6 +849,40 @@ __global__ __launch_bounds__(PL::NT, (fft2_waves<PL>())) void k_fft2(PipeArgs<fl
         }
         o0[k] = mk<T>(y.re.x, y.im.x);
         if (has1) o1[k] = mk<T>(y.re.y, y.im.y);
+      }
+    }
+  }
+  if constexpr (GKEY) {
+    // merge, count out, and let the last workgroup decode + clear the key (the scheme of k_zf2p's epilogue; the
+    // launcher hands this mode a {head, done} counter pair)
+    const unsigned lane = (unsigned)t & (XM_WAVE - 1u);
+    if (have && lane == 0u)
+      atomicMax(A.gkey + (blockIdx.x % XM_KEY_SLOTS) * XM_KEY_STRIDE,
+                ((unsigned long long)best_key << 32) | (unsigned long long)(0xffffffffu - best_row));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned last = 0;
+    if (t == 0) {
+      const unsigned d = atomicAdd(A.queue + 1, 1u);
+      last = d == gridDim.x - 1u;
+      if (last) __hip_atomic_store(A.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (A.key_result && t < XM_WAVE) {  // first wave: one partial key per lane
+      last = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
+      if (last) {
+        unsigned long long k = __hip_atomic_load(A.gkey + t * XM_KEY_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.gkey + t * XM_KEY_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int m = XM_WAVE / 2; m >= 1; m >>= 1) {
+          const unsigned hi = (unsigned)__shfl_xor((int)(k >> 32), m, XM_WAVE), lo = (unsigned)__shfl_xor((int)(unsigned)k, m, XM_WAVE);
+          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+          k = o > k ? o : k;
+        }
+        if (t == 0) {
+          const unsigned row = k ? 0xffffffffu - (unsigned)(k & 0xffffffffu) : 0u;  // nothing published: row 0
+          A.key_result->max2 = __uint_as_float((unsigned)(k >> 32));
+          A.key_result->flat = (long long)row * (long long)N;
+        }
       }
     }
   }

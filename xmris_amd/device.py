@@ -357,11 +357,13 @@ def ramp_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho
 
 def key_native(x2, n_out: int, pad_left: int = 0, shift_out: bool = True, ortho: bool = True) -> bool:
     """True when `pipeline_fused(global_key=, key_result=)` is available for this geometry and dtype (complex64: the
-    geometries of `ramp_native`; complex128: half lengths 4096 and 8192)."""
+    geometries of `ramp_native` -- without a >= 2x zero fill only in the `phase_ramp=` form; complex128: half lengths
+    4096 and 8192)."""
     _require_device(x2)
     flags = (_lib.XM_FFT_ORTHO if ortho else 0) | (_lib.XM_FFT_SHIFT_OUT if shift_out else 0)
-    return bool(_lib.load().xm_pipeline_key_native(x2.data_ptr(), x2.shape[1], x2.shape[1], int(n_out), int(pad_left),
-                                                   flags, _dtype_code(x2)))
+    # (the kernels without a >= 2x zero fill pack two rows per lane pair: a single row takes another kernel)
+    return x2.shape[0] >= 2 and bool(_lib.load().xm_pipeline_key_native(x2.data_ptr(), x2.shape[1], x2.shape[1], int(n_out),
+                                                                       int(pad_left), flags, _dtype_code(x2)))
 
 
 def pipeline_fused(x2, n_out: int, pad_left: int = 0, window=None, phase_table=None, shift_out: bool = True,
