@@ -273,8 +273,7 @@ def test_speculative_guess_on_a_subset_misses_and_is_repaired(mods, monkeypatch,
 @pytest.mark.parametrize("dtype,nt,target", [("complex128", 1024, 2048), ("complex128", 4096, 8192), ("complex64", 1536, 1536),
                                              ("complex64", 1000, 2048), ("complex64", 8192, 16384),
                                              # no zero fill on k_fft2's plans: the arg-max key of its ramp mode (round 4)
-                                             ("complex64", 2048, 2048), ("complex64", 768, 768), ("complex64", 6144, 6144),
-                                             ("complex64", 512, 512)])
+                                             ("complex64", 2048, 2048), ("complex64", 768, 768), ("complex64", 6144, 6144)])
 def test_speculative_schedule_on_the_table_and_per_row_paths(mods, dtype, nt, target):
     """The speculative schedule where the packed complex64 kernel does not apply: complex128 (`k_zf2<double>` /
     `k_zf2d` with the ramp, per-row maxima + reductions instead of arg-max keys) and no zero fill / mixed radix /
