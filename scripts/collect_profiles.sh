@@ -10,9 +10,11 @@
 #             pmc_guess_kernel.txt, pmc_prepass_kernel.txt; complex128 main kernel at 65,536 voxels -> pmc_c128_main.txt
 #             (scripts/pmc_json.py turns the two main-kernel files into the JSON bench.py reads for roofline.traffic)
 #   labs      the small timing scripts: guess stage, heterogeneous family, host path, C1 tolerance, configs, FFT sweep,
-#             c128 kernel modes, 6-rank shared-GPU rehearsal of the host budget
+#             c128 kernel modes, 6-rank shared-GPU rehearsal of the host budget; round 4: the device search against the
+#             host engine (check_device_search.py), zero fill + apodisation in one launch, the search engines and the
+#             searches-in-flight sweep on one box, the `configs` record alone
 set -e -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 shift || true
 parts=${*:-bench stats pmc labs}
 out=gpurun_out/$tag
@@ -60,6 +62,11 @@ if has labs; then
   NSETS=12 python3 scripts/time_hetero.py > $out/hetero_steps.txt 2>/dev/null
   python3 scripts/time_accessor_host_path.py > $out/host_path.txt 2>/dev/null
   python3 scripts/c1_tolerance.py > $out/c1_tolerance.txt 2>/dev/null
+  python3 scripts/check_device_search.py > $out/device_search.txt 2>/dev/null || true   # (two degenerate slices diverge: exit 1)
+  python3 scripts/time_zf_apod.py > $out/zf_apod.txt 2>/dev/null
+  bash scripts/ab_search_engines.sh > $out/search_engines.txt 2>/dev/null; rm -f gpurun_out/ab_*.json gpurun_out/ab.err
+  bash scripts/sweep_search_workers.sh > $out/search_workers.txt 2>/dev/null; rm -f gpurun_out/sw_*.json gpurun_out/sw.err
+  python3 bench.py --only-configs --no-cpu-baseline > $out/configs.json 2>/dev/null
   python3 scripts/time_configs.py > $out/time_configs.txt 2>/dev/null || true
   python3 scripts/time_fft_sweep.py > $out/fft_sweep.txt 2>/dev/null || true
   python3 scripts/time_c128_modes.py > $out/c128_modes.txt 2>/dev/null || true

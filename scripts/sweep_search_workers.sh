@@ -1,3 +1,4 @@
+# BASELINE configs[1] / configs[4] end to end (host engine) over searches in flight x team budget.
 for w in 4 6 8; do for th in "" 8 16; do
   name="w${w}_t${th:-auto}"
   if [ -n "$th" ]; then export XM_SOLVER_THREADS=$th; else unset XM_SOLVER_THREADS; fi

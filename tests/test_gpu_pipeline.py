@@ -355,9 +355,9 @@ def test_speculative_schedule_two_ranks_with_cross_rank_repair():
 
 
 @pytest.mark.parametrize("engine", ["host", "device"])
-def test_speculative_schedule_five_ranks_share_the_gpu(engine):
-    """FIVE ranks (with this process that is the six the GPU box allows on its card) share the GPU and run
-    run_stream(speculate=True) on shards of twelve datasets: winners rotating over ranks 1..4, rank 0 never an owner,
+def test_speculative_schedule_four_ranks_share_the_gpu(engine):
+    """FOUR ranks (the GPU box allows six processes on its card: this one, the four, and one to spare) share the GPU and
+    run run_stream(speculate=True) on shards of twelve datasets: winners rotating over ranks 1..3, rank 0 never an owner,
     two cross-rank repairs -- with the searches on the library's native host threads and as search kernels on reserved
     CUs.  scripts/check_spec_ranks.py asserts, on every rank, the one-rank classic result bit for bit ((p0, p1), pivot,
     flat index), the gathered spectra to 1e-6, and equal exchange / broadcast call counts across the ranks."""
@@ -372,11 +372,11 @@ def test_speculative_schedule_five_ranks_share_the_gpu(engine):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, XMRIS_AMD_SEARCH=engine)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", "check_spec_ranks.py")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "5-rank speculative run_stream" in r.stdout and ": OK" in r.stdout
+    assert "4-rank speculative run_stream" in r.stdout and ": OK" in r.stdout
     print(r.stdout[-1500:])
 
 

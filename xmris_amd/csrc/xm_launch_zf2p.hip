@@ -58,7 +58,7 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
     // value-only maxima are accumulated with one atomic max per wave: the slots start at +0.0
     if (A.amax_value_only && !A.gkey) HIP_TRY(hipMemsetAsync(A.absmax2, 0, (size_t)A.n_batch * sizeof(T), st));
   }
-  if constexpr ((OPT & (ZF2P_QUEUE | ZF2P_CAND)) != 0) {
+  if constexpr ((OPT & (ZF2P_QUEUE | ZF2P_CAND)) != 0 || ((MODE & ZF2_AMAX) != 0 && (MODE & ZF2_WRITE) != 0)) {
     rc = xm_queue_slot(&A.queue);
     if (rc) return rc;
   }
@@ -72,6 +72,21 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
 // arg-max-only pre-pass is instruction bound (every workgroup takes the same time per row): static stride.
 constexpr int kOptWrite = ZF2P_LOAD16 | ZF2P_NT | ZF2P_QUEUE;
 constexpr int kOptAmax = ZF2P_LOAD16;
+
+// Short launches (a few dozen rows per workgroup: BASELINE configs[1], 16,384 x 2048 -> 4096, is 0.17 ms) gain nothing
+// from the row queue -- its point is the tail of millisecond launches -- and pay for its tickets: the ramp modes are
+// also built with the static split, chosen below `XM_ZF2P_STATIC_ROWS` rows per resident workgroup (tuning switch;
+// default set from the same-box A/B in profiles/r04/time_configs.txt).
+constexpr int kOptWriteStatic = ZF2P_LOAD16 | ZF2P_NT;
+
+template <class PL, int MODE>
+int launch_write(const PipeArgs<T>& A, hipStream_t st) {
+  static const long long static_rows = getenv("XM_ZF2P_STATIC_ROWS") ? atoll(getenv("XM_ZF2P_STATIC_ROWS")) : 0;
+  int cus = 0;
+  if (static_rows > 0 && xm_stream_cu_count(st, &cus) == XM_OK && cus > 0 && A.n_batch < static_rows * 2 * cus)
+    return launch_mode<PL, MODE, kOptWriteStatic>(A, st);
+  return launch_mode<PL, MODE, kOptWrite>(A, st);
+}
 
 template <class PL>
 int launch_plan(PipeArgs<T> A, const double* ramp, hipStream_t st) {
@@ -89,8 +104,7 @@ int launch_plan(PipeArgs<T> A, const double* ramp, hipStream_t st) {
     A.ramp_e[1] = (T)std::sin(ramp[1]);
     A.ramp_db = ramp[1];
     A.phase = nullptr;
-    return am ? launch_mode<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX, kOptWrite>(A, st)
-              : launch_mode<PL, ZF2_WRITE | ZF2_RAMP, kOptWrite>(A, st);
+    return am ? launch_write<PL, ZF2_WRITE | ZF2_RAMP | ZF2_AMAX>(A, st) : launch_write<PL, ZF2_WRITE | ZF2_RAMP>(A, st);
   }
   if (wr && ph && am) return launch_mode<PL, ZF2_WRITE | ZF2_PHASE | ZF2_AMAX, kOptWrite>(A, st);
   if (wr && ph) return launch_mode<PL, ZF2_WRITE | ZF2_PHASE, kOptWrite>(A, st);

@@ -442,7 +442,8 @@ __global__ __launch_bounds__(PL::NT, (zf2_waves<float, PL>())) void k_zf2p(PipeA
       atomicMax(A.gkey + (blockIdx.x % XM_KEY_SLOTS) * XM_KEY_STRIDE,
                 ((unsigned long long)best_key << 32) | (unsigned long long)(0xffffffffu - best_row));
   }
-  if constexpr (QUEUE || CAND) {  // the last workgroup out leaves the counters at zero for the next launch
+  if constexpr (QUEUE || CAND || (AMAX && WRITE)) {  // the last workgroup out leaves the counters at zero for the next launch
+    // (static write modes with maxima count out too: their key is decoded here like the queued modes')
     // ... and, asked to (A.key_result / A.take_flat), merges the partial keys into the caller's result record: every
     // wave's atomic is acknowledged (vmcnt) before its workgroup counts itself out, so the last one sees them all
     bool decode = false;
