@@ -52,7 +52,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # MI355X_MICROARCH.md section HBM -- plus WRITE_SIZE, exact for 16-byte streaming stores).  bench.py reads that file and
 # refuses the number (traffic: null) when the kernel it launches or the workload differs from what was profiled: a
 # figure from another kernel cannot go stale silently.
-PMC_FILES = {"c64": "profiles/r03/pmc_main_kernel.json", "c128": "profiles/r03/pmc_c128_main.json"}
+PMC_FILES = {"c64": "profiles/r04/pmc_main_kernel.json", "c128": "profiles/r04/pmc_c128_main.json"}
 
 
 def pmc_traffic(dtype_key, kernel_name, nv, nt, N):
