@@ -301,6 +301,9 @@ int xm_hostsearch_submit(const void* slice, int n, const double* coords, int met
                          int p0_only, unsigned seed, double tol, int maxiter, int threads, uint64_t seq,
                          xm_search_result* out);
 
+/* searches the service runs side by side (1 ... 8, default 4): further submissions wait in its queue, in order */
+int xm_hostsearch_set_workers(int n);
+
 /* ---- streams with a partition of the chip.  A search kernel (above) needs a whole CU's registers for milliseconds,
  * and the streaming kernels are persistent grids sized to fill every CU: sharing one pool of CUs, searches wait for a
  * kernel boundary to start and the streaming kernels then find CUs taken (measured: main pass +7 %, stalls of

@@ -77,6 +77,7 @@ SIGNATURES = {
                               ctypes.c_uint64, _p, _p]),
     "xm_search_eval": (_i, [_p, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _i, _p, _i, _p, _p]),
     "xm_hostsearch_submit": (_i, [_p, _i, _p, _i, _i, _i, _i, _u, ctypes.c_double, _i, _i, ctypes.c_uint64, _p]),
+    "xm_hostsearch_set_workers": (_i, [_i]),
     "xm_stream_create": (_i, [_p, _i, _i]),
     "xm_stream_destroy": (_i, [_p]),
     "xm_stream_cus": (_i, [_p]),

@@ -37,6 +37,7 @@ struct Service {
   std::deque<Job> queue;
   std::vector<std::thread> workers;
   int idle = 0;
+  int max_workers = 4;  // searches running at once (xm_hostsearch_set_workers); more submissions wait in the queue
   bool quit = false;
 
   void run_job(const Job& j) {
@@ -144,11 +145,25 @@ int xm_hostsearch_submit(const void* slice, int n, const double* coords, int met
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->queue.push_back(j);
-    // a worker per search in flight, at most eight: one more whenever none is idle to take this job
-    if (s->idle < (int)s->queue.size() && s->workers.size() < 8) s->workers.emplace_back([s] { s->worker(); });
+    // one more worker whenever none is idle to take this job, up to the cap: later submissions wait their turn (the
+    // executor submits further ahead than it wants searches to run side by side)
+    if (s->idle < (int)s->queue.size() && (int)s->workers.size() < s->max_workers) s->workers.emplace_back([s] { s->worker(); });
   }
   s->cv.notify_one();
   return XM_OK;
+}
+
+// searches the service runs side by side (1 ... 8; default 4); returns the value set.  Workers already started stay.
+int xm_hostsearch_set_workers(int n) {
+  Service* s;
+  {
+    std::lock_guard<std::mutex> lk(g_service_mu);
+    if (!g_service) g_service = new Service();
+    s = g_service;
+  }
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->max_workers = n < 1 ? 1 : (n > 8 ? 8 : n);
+  return s->max_workers;
 }
 
 }  // extern "C"

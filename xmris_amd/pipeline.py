@@ -423,6 +423,21 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
     return w, team_of(w)
 
 
+def _look_ahead(workers: int, n_sets: int, overlap: bool, polish: str) -> int:
+    """Datasets whose searches are SUBMITTED ahead of the main pass being queued.  `workers` of them run side by side;
+    with the native search service (polish="exact") three more wait in its queue: a search then ends five or six device
+    periods before its result is needed instead of two, which is what hides the rare search whose polish has to run on
+    the reference's route (scipy's minimiser on the numpy objective: 3-8 ms) -- on the heterogeneous dataset family
+    one search in seven needs it, and with the polish done by the launch thread when the result was collected the rate
+    fell from 46 to 33 M spectra/s (profiles/r04/hetero_steps.txt)."""
+    if not overlap:
+        return 0
+    if n_sets <= 2:
+        return 1
+    extra = 3 if polish == "exact" else 0
+    return min(workers + extra, n_sets - 1)
+
+
 def _search_team(workers: int) -> int:
     """Threads per search with `workers` searches in flight (`autophase_solver.stream_threads`: more than three in
     flight means the host paces the steps)."""
@@ -494,8 +509,8 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
             workers, use_dev, dev_ahead = int(round(got[0])), use_dev and got[1] > 0, int(round(got[1]))
         else:
             workers, use_dev, dev_ahead = 2, False, 0
-    s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
-    cpu_fill = min(n_sets, s_ahead + 1) if use_dev else n_sets
+    s_ahead = _look_ahead(workers, n_sets, overlap, polish)
+    cpu_fill = min(n_sets, min(workers, s_ahead) + 1) if use_dev else n_sets
     use_dev = use_dev and cpu_fill < n_sets
     eng = dict(workers=workers, team=team, use_dev=use_dev, dev_ahead=dev_ahead, est_ms=est_ms if use_dev else 0.0,
                axis=axis, search_streams=None)
@@ -544,7 +559,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     rd = torch.float32 if x0.dtype == torch.complex64 else torch.float64
     workers, team, use_dev, dev_ahead, est_ms, axis = (eng["workers"], eng["team"], eng["use_dev"], eng["dev_ahead"],
                                                         eng["est_ms"], eng["axis"])
-    s_ahead = (min(workers, n_sets - 1) if n_sets > 2 else 1) if overlap else 0
+    s_ahead = _look_ahead(workers, n_sets, overlap, polish)
     # (round 3: the selection stage of dataset j on a stream of its own beside the coarse spectra of dataset j + 1,
     # gated so that it never shares the chip with a main pass, hides nothing -- the coarse-spectra kernel fills the
     # chip, 1.20 vs 1.20 ms per step; let loose beside the main kernel it costs 6 %.  Only the winner's fp64 spectrum
@@ -553,7 +568,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     g_ahead = s_ahead + 1 if overlap else 0                # guess kernels queued ahead of it
     # device engine: the first `cpu_fill` datasets of the call are searched by the host engine (s_ahead at a time);
     # from then on a dataset's search is a kernel that starts `dev_ahead` datasets before its main pass
-    cpu_fill = min(n_sets, s_ahead + 1) if use_dev else n_sets
+    cpu_fill = min(n_sets, min(workers, s_ahead) + 1) if use_dev else n_sets
     use_dev = use_dev and cpu_fill < n_sets
     if use_dev:
         g_ahead = max(g_ahead, min(dev_ahead, n_sets - 1))
@@ -635,7 +650,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     if sub_step is None:
         sub_step = plan.extra["guess_sub_step"] = max(1, int(os.environ.get("XM_GUESS_SUBSTEP", "8")))
     # searches in flight at once share the host: each gets an equal part of the team
-    n_workers = s_ahead if s_ahead >= 2 else 0
+    n_workers = min(workers, s_ahead) if s_ahead >= 2 else 0  # searches RUNNING side by side (more may be queued)
     team = _search_team(n_workers) if n_workers else aps.stream_threads()  # per search in flight
     pool = None
     if n_workers:
@@ -658,6 +673,43 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)], seq=[0], retired=[])
         if plan.extra.get("freq_c") is None:
             plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
+        from . import _lib as _lib_mod
+
+        _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers) + 1)  # (+ 1: a search that is started a second time)
+    # Searches that do not pass scipy's projected-gradient test are polished on the reference's route (numpy objective,
+    # milliseconds of interpreter): a helper thread starts on that as soon as the search's record says so -- the launch
+    # thread looks at the records of the searches in flight once per dataset -- instead of the launch thread doing it
+    # when it needs the result.
+    polish_pool = plan.extra.get("polish_pool")
+    if polish_pool is None:
+        polish_pool = plan.extra["polish_pool"] = ThreadPoolExecutor(max_workers=2, thread_name_prefix="xm-polish")
+    polish_futs = {}
+
+    def advance_polishes():
+        for j, (_, fut_j, _) in pending.items():
+            if j in polish_futs or not (isinstance(fut_j, tuple) and len(fut_j) == 2 and fut_j[0] in ("host", "dev")):
+                continue
+            rec = (hsearch if fut_j[0] == "host" else dsearch)["recs"][j % ring]
+            if not dev.search_done(rec, fut_j[1]):
+                continue
+            r = dev.read_search_record(rec)
+            if not r["needs_polish"]:
+                polish_futs[j] = None
+                continue
+            k = r["target_idx"]
+            sl = sel[j % ring].h_slice[0].numpy().copy()
+            polish_futs[j] = polish_pool.submit(aps.polish_reference, sl, plan.freq, float(plan.freq[k]), k, iw, method,
+                                                p0_only, r["x"])
+
+    def polished(i, r, k, b):
+        """(x, fun, nfev of the polish) of a search that needs one: the helper thread's, or done here."""
+        fut = polish_futs.pop(i, None)
+        if fut is not None:
+            x, fun, nfev_p, _ = fut.result()
+            return x, fun, nfev_p
+        sl = sel[b].h_slice[0].numpy().copy()
+        x, fun, nfev_p, _ = aps.polish_reference(sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+        return x, fun, nfev_p
 
     def submit_host_search(j, k, threads, rec):
         """`xm_hostsearch_submit` of dataset j's slice (pinned, in its selection slot); returns the sequence number."""
@@ -719,11 +771,13 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         timing = {"generations_ms": 1e-3 * r["t_us"][0], "polish_ms": 1e-3 * (r["t_us"][5] - r["t_us"][0])}
         if r["needs_polish"]:
             t0 = time.perf_counter()
-            sl = sel[b].h_slice[0].numpy().copy()
-            x, fun, nfev_p, _ = aps.polish_reference(sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+            x, fun, nfev_p = polished(i, r, k, b)
             p0, p1 = float(x[0]), (float(x[1]) if not p0_only else 0.0)
             nfev = r["nfev"] + nfev_p
-            timing["polish_ms"] = 1e3 * (time.perf_counter() - t0)
+            timing["polish_ms"] = 1e3 * (time.perf_counter() - t0)  # (what the launch thread still waited for)
+            timing["polish_route"] = "numpy"
+        else:
+            polish_futs.pop(i, None)
         return p0, (p1 if not p0_only else 0.0), nfev, fun, timing, hedged
 
     def guess(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
@@ -807,11 +861,13 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         timing = {"generations_ms": 1e-3 * r["t_us"][5], "polish_ms": 0.0, "device": True}
         if r["needs_polish"]:
             t0 = time.perf_counter()
-            sl = sel[b].h_slice[0].numpy().copy()
-            x, fun, nfev_p, _ = aps.polish_reference(sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+            x, fun, nfev_p = polished(i, r, k, b)
             p0, p1 = float(x[0]), (float(x[1]) if not p0_only else 0.0)
             nfev = r["nfev"] + nfev_p
             timing["polish_ms"] = 1e3 * (time.perf_counter() - t0)
+            timing["polish_route"] = "numpy"
+        else:
+            polish_futs.pop(i, None)
         return p0, (p1 if not p0_only else 0.0), k, nfev, fun, timing, False
 
     # the pipeline-filling search (the first main pass waits for it) takes the whole CPU share for its millisecond:
@@ -986,6 +1042,8 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         while guessed < min(n_sets - 1, i + g_ahead):
             guessed += 1
             guess(guessed)
+        if use_service or use_dev:
+            advance_polishes()
         res, fut, search_args = pending.pop(i)
         ev["t_collect"] = time.perf_counter()
         if isinstance(fut, tuple) and len(fut) == 2 and fut[0] == "dev":  # a search kernel
