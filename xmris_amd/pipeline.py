@@ -434,8 +434,10 @@ def _look_ahead(workers: int, n_sets: int, overlap: bool, polish: str) -> int:
         return 0
     if n_sets <= 2:
         return 1
-    extra = 3 if polish == "exact" else 0
-    return min(workers + extra, n_sets - 1)
+    import os
+
+    extra = int(os.environ.get("XM_SEARCH_QUEUE_EXTRA", "3")) if polish == "exact" else 0  # (tuning switch)
+    return min(workers + max(0, extra), n_sets - 1)
 
 
 def _search_team(workers: int) -> int:
@@ -675,7 +677,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
         from . import _lib as _lib_mod
 
-        _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers) + 1)  # (+ 1: a search that is started a second time)
+        # (as many as run side by side: with spinning teams, one search more than the thread budget was cut for
+        # oversubscribes the cores; a hedged second start raises the cap for itself)
+        _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers))
     # Searches that do not pass scipy's projected-gradient test are polished on the reference's route (numpy objective,
     # milliseconds of interpreter): a helper thread starts on that as soon as the search's record says so -- the launch
     # thread looks at the records of the searches in flight once per dataset -- instead of the launch thread doing it
@@ -755,7 +759,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 last_hedge[0] = i
                 spare = torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64)  # (its own record: see above)
                 hsearch["retired"].append(spare)
+                _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers) + 1)  # (it must not wait in the queue)
                 second = (spare, submit_host_search(i, k, fill_team, spare))
+                _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers))
                 hedged = True
             if now > give_up:
                 raise RuntimeError("the search service did not answer within two minutes")
