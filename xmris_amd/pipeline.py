@@ -686,7 +686,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     # when it needs the result.
     polish_pool = plan.extra.get("polish_pool")
     if polish_pool is None:
-        polish_pool = plan.extra["polish_pool"] = ThreadPoolExecutor(max_workers=2, thread_name_prefix="xm-polish")
+        # (six threads, XM_POLISH_THREADS: numpy releases the interpreter lock inside its loops over an 8192-bin axis, so polishes of
+        # different datasets run side by side; on the heterogeneous family 13 searches of 16 need one)
+        polish_pool = plan.extra["polish_pool"] = ThreadPoolExecutor(max_workers=int(os.environ.get("XM_POLISH_THREADS", "6")), thread_name_prefix="xm-polish")
     polish_futs = {}
 
     def advance_polishes():
