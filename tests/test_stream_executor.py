@@ -112,7 +112,8 @@ def test_speculative_executor_equals_classic_single_process(monkeypatch):
 
 def _rank_main(rank, world, port, engine, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_WORLD_SIZE=str(world), XM_SOLVER_THREADS="1", XMRIS_AMD_SEARCH=engine)
+                      LOCAL_WORLD_SIZE=str(world), XM_SOLVER_THREADS="1", XMRIS_AMD_SEARCH=engine,
+                      XM_POLISH_THREADS="1")  # (polish helpers on a thread: eight ranks x four worker processes is a crowd)
     if engine == "host":
         os.environ["XM_HEDGE_SPACING"] = "1"  # (a rank owns every seventh dataset here: the one-in-eight rule would never let it hedge twice)
         os.environ["XM_TEST_SLOW_SEARCH"] = "7,4000"  # dataset 7's search reaches its owner's search service 4 s late: started a second time

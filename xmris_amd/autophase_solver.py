@@ -437,6 +437,96 @@ def polish_reference(sl, coords, pivot, target_idx, index_width, method, p0_only
     return x, fun, int(res.nfev), False
 
 
+class PolishWorkers:
+    """A few worker PROCESSES (`xmris_amd/_polish_worker.py`, started as plain children: `python -c ...`, no fork of
+    this process, no re-import of its main module) that run `polish_reference` away from this process's interpreter
+    lock.  `submit(...)` takes `polish_reference`'s arguments and returns a future; a worker that cannot be started or
+    dies mid-request makes the future's thread do the polish itself."""
+
+    def __init__(self, n: int = 4):
+        import os
+        import queue
+        import subprocess
+        import sys
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._free = queue.Queue()
+        self._procs = []
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
+                   OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        for _ in range(max(1, n)):
+            try:
+                pr = subprocess.Popen([sys.executable, "-c", "from xmris_amd import _polish_worker as w; w.main()"],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
+            except OSError:
+                break
+            self._procs.append(pr)
+            self._free.put(pr)
+        # (threads that only wait on a pipe: they hold the interpreter lock for microseconds per request)
+        self._pool = ThreadPoolExecutor(max_workers=max(1, len(self._procs)), thread_name_prefix="xm-polish")
+        import atexit
+
+        atexit.register(self.close)
+
+    def submit(self, *args):
+        return self._pool.submit(self._call, args)
+
+    def _call(self, args):
+        import pickle
+        import struct
+
+        pr = None
+        try:
+            pr = self._free.get(timeout=60.0) if self._procs else None
+            if pr is not None and pr.poll() is None:
+                blob = pickle.dumps(args, protocol=pickle.HIGHEST_PROTOCOL)
+                pr.stdin.write(struct.pack("<q", len(blob)))
+                pr.stdin.write(blob)
+                pr.stdin.flush()
+                head = pr.stdout.read(8)
+                if len(head) == 8:
+                    status, value = pickle.loads(pr.stdout.read(struct.unpack("<q", head)[0]))
+                    if status == "ok":
+                        return value
+        except Exception:  # noqa: BLE001 -- any trouble with a worker: this thread does the polish
+            pass
+        finally:
+            if pr is not None and pr.poll() is None:
+                self._free.put(pr)
+        return polish_reference(*args)
+
+    def close(self):
+        for pr in self._procs:
+            try:
+                pr.stdin.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for pr in self._procs:
+            try:
+                pr.wait(timeout=2.0)
+            except Exception:  # noqa: BLE001
+                pr.kill()
+            try:
+                pr.stdout.close()
+            except Exception:  # noqa: BLE001
+                pass
+        self._procs = []
+
+
+_POLISH_WORKERS = None
+
+
+def polish_workers():
+    """The process-wide `PolishWorkers` (created on first use; `XM_POLISH_WORKERS` = how many, default 4)."""
+    import os
+
+    global _POLISH_WORKERS
+    if _POLISH_WORKERS is None:
+        _POLISH_WORKERS = PolishWorkers(int(os.environ.get("XM_POLISH_WORKERS", "4")))
+    return _POLISH_WORKERS
+
+
 def _solve_native(sl, coords, pivot, target_idx, index_width, method, p0_only, threads=None, polish="exact"):
     """scipy's differential_evolution(best1bin, tol=0.01, seed=42) restated natively: the generations
     run in libxmris_hip.so (same RandomState stream, same trial vectors as scipy given equal objective

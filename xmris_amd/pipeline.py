@@ -684,11 +684,18 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     # milliseconds of interpreter): a helper thread starts on that as soon as the search's record says so -- the launch
     # thread looks at the records of the searches in flight once per dataset -- instead of the launch thread doing it
     # when it needs the result.
+    # ... and that helper is a worker PROCESS (`autophase_solver.PolishWorkers`): a polish is milliseconds of small numpy
+    # operations, and on helper THREADS they were taken out of this thread's share of the interpreter lock -- on the
+    # heterogeneous family, where 13 searches of 16 need the polish, the launch thread fell from 1.4 to 2.3 ms per
+    # dataset (profiles/r04/hetero_polish.txt).  XM_POLISH_THREADS=1 keeps them on threads of this process.
     polish_pool = plan.extra.get("polish_pool")
     if polish_pool is None:
-        # (six threads, XM_POLISH_THREADS: numpy releases the interpreter lock inside its loops over an 8192-bin axis, so polishes of
-        # different datasets run side by side; on the heterogeneous family 13 searches of 16 need one)
-        polish_pool = plan.extra["polish_pool"] = ThreadPoolExecutor(max_workers=int(os.environ.get("XM_POLISH_THREADS", "6")), thread_name_prefix="xm-polish")
+        if os.environ.get("XM_POLISH_THREADS"):
+            polish_pool = ThreadPoolExecutor(max_workers=max(1, int(os.environ["XM_POLISH_THREADS"])), thread_name_prefix="xm-polish")
+        elif n_sets > 4:  # (a stream: the workers start now, in the background -- a process start + scipy's import is ~1 s)
+            polish_pool = aps.polish_workers()
+        if polish_pool is not None:
+            plan.extra["polish_pool"] = polish_pool
     polish_futs = {}
 
     def advance_polishes():
@@ -704,8 +711,12 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 continue
             k = r["target_idx"]
             sl = sel[j % ring].h_slice[0].numpy().copy()
-            polish_futs[j] = polish_pool.submit(aps.polish_reference, sl, plan.freq, float(plan.freq[k]), k, iw, method,
-                                                p0_only, r["x"])
+            args = (sl, plan.freq, float(plan.freq[k]), k, iw, method, p0_only, r["x"])
+            if polish_pool is None:  # (a short call: the launch thread polishes when it collects the result)
+                polish_futs[j] = None
+            else:
+                polish_futs[j] = (polish_pool.submit(aps.polish_reference, *args) if isinstance(polish_pool, ThreadPoolExecutor)
+                                  else polish_pool.submit(*args))
 
     def polished(i, r, k, b):
         """(x, fun, nfev of the polish) of a search that needs one: the helper thread's, or done here."""
