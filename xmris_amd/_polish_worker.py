@@ -15,6 +15,11 @@ import sys
 def main():
     from xmris_amd import autophase_solver as aps
 
+    try:  # (now, while nobody waits: the first request must not pay for scipy's import)
+        import scipy.optimize  # noqa: F401
+        from scipy.optimize import _lbfgsb  # noqa: F401
+    except ImportError:
+        pass
     inp, out = sys.stdin.buffer, sys.stdout.buffer
     sys.stdout = sys.stderr  # (anything a library prints must not end up in the reply stream)
     while True:
