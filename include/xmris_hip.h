@@ -294,7 +294,8 @@ int xm_search_eval(const void* slice, int n, double c0, double cstep, double x_r
 /* ---- A7 on the host without the interpreter: the same search -- xm_solver_de's generations, then the projected-
  * gradient test of the polish (xm_solver_fg) -- run by a native thread of the library's search service; `out` (HOST
  * memory) is filled like a search kernel fills it, `seq` last (poll it with xm_atomic_load_acquire_i64).  `slice`
- * (n complex128, host-readable) and `coords` (n float64) must stay valid until then.  `target_idx` < 0: the first
+ * (n complex128, host-readable) and `coords` (n float64) are copied at submission; `out` must stay valid until the
+ * search has ended.  `target_idx` < 0: the first
  * arg-max of |slice| (phasing.py:229); the pivot is coords[target_idx].  `threads`: team size of the generations
  * (<= 0: the library's default).  Returns at once. */
 int xm_hostsearch_submit(const void* slice, int n, const double* coords, int method, int target_idx, int index_width,

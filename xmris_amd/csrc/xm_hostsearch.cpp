@@ -22,6 +22,10 @@
 namespace {
 
 struct Job {
+  // the service's OWN copies of the slice and the axis: a search that was started a second time (or submitted late by
+  // a test hook) may still be running when its caller has moved on and freed the buffers it was submitted from --
+  // only the result record must outlive it (the executor keeps abandoned records alive)
+  std::vector<double> slice_copy, coords_copy;
   const double* slice;
   const double* coords;
   xm_search_result* out;
@@ -103,9 +107,11 @@ struct Service {
         cv.wait(lk, [&] { return quit || !queue.empty(); });
         --idle;
         if (quit) return;
-        j = queue.front();
+        j = std::move(queue.front());
         queue.pop_front();
       }
+      j.slice = j.slice_copy.data();
+      j.coords = j.coords_copy.data();
       run_job(j);
     }
   }
@@ -129,8 +135,10 @@ int xm_hostsearch_submit(const void* slice, int n, const double* coords, int met
     s = g_service;
   }
   Job j;
-  j.slice = (const double*)slice;
-  j.coords = coords;
+  j.slice_copy.assign((const double*)slice, (const double*)slice + 2 * (size_t)n);
+  j.coords_copy.assign(coords, coords + n);
+  j.slice = nullptr;  // (set from the copies by the worker: the vectors move with the job)
+  j.coords = nullptr;
   j.out = out;
   j.seq = seq;
   j.tol = tol;
@@ -144,7 +152,7 @@ int xm_hostsearch_submit(const void* slice, int n, const double* coords, int met
   j.seed = seed;
   {
     std::lock_guard<std::mutex> lk(s->mu);
-    s->queue.push_back(j);
+    s->queue.push_back(std::move(j));
     // one more worker whenever none is idle to take this job, up to the cap: later submissions wait their turn (the
     // executor submits further ahead than it wants searches to run side by side)
     if (s->idle < (int)s->queue.size() && (int)s->workers.size() < s->max_workers) s->workers.emplace_back([s] { s->worker(); });

@@ -423,6 +423,15 @@ def _search_workers(plan: PipelinePlan, n_rows: int, elem_bytes: int, threads: i
     return w, team_of(w)
 
 
+_ABANDONED_RECORDS = []  # result records of searches nobody waits for any more (a hedged search's loser, a test hook's
+                          # late submission): their searches still write them when they end, so they must not be freed
+
+
+def _abandon(rec):
+    _ABANDONED_RECORDS.append(rec)
+    del _ABANDONED_RECORDS[:-256]
+
+
 def _look_ahead(workers: int, n_sets: int, overlap: bool, polish: str) -> int:
     """Datasets whose searches are SUBMITTED ahead of the main pass being queued.  `workers` of them run side by side;
     with the native search service (polish="exact") three more wait in its queue: a search then ends five or six device
@@ -672,7 +681,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         hsearch = plan.extra.get(("host_search", ring))
         if hsearch is None:
             hsearch = plan.extra[("host_search", ring)] = dict(
-                recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)], seq=[0], retired=[])
+                recs=[torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64) for _ in range(ring)], seq=[0])
         if plan.extra.get("freq_c") is None:
             plan.extra["freq_c"] = np.ascontiguousarray(plan.freq, dtype=np.float64)
         from . import _lib as _lib_mod
@@ -762,8 +771,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             if second is not None and dev.search_done(second[0], second[1]):
                 # the first submission is still on its way: it will write its record whenever it ends, so that record
                 # leaves the ring (a later dataset's result in the same slot must not be overwritten by it)
-                hsearch["retired"].append(rec)
-                del hsearch["retired"][:-64]
+                _abandon(rec)
                 hsearch["recs"][b] = torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64)
                 rec = second[0]
                 break
@@ -771,7 +779,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             if can_hedge and second is None and now > deadline:
                 last_hedge[0] = i
                 spare = torch.zeros(dev.SEARCH_RECORD_WORDS, dtype=torch.int64)  # (its own record: see above)
-                hsearch["retired"].append(spare)
+                _abandon(spare)
                 _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers) + 1)  # (it must not wait in the queue)
                 second = (spare, submit_host_search(i, k, fill_team, spare))
                 _lib_mod.load().xm_hostsearch_set_workers(max(1, n_workers))
@@ -832,7 +840,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         if dsearch is None:
             dsearch = plan.extra[("dev_search", ring)] = dict(
                 recs=[dev.new_search_record() for _ in range(ring)],
-                streams=[torch.cuda.Stream(device=x0.device) for _ in range(min(ring, 16))], seq=[0], retired=[])
+                streams=[torch.cuda.Stream(device=x0.device) for _ in range(min(ring, 16))], seq=[0])
         if eng["search_streams"] is not None:  # the search partition of the chip (see _run_stream_speculative)
             dsearch["streams"] = list(eng["search_streams"])
 
@@ -864,7 +872,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 p0, p1, opt = search(sl, k, float(plan.freq[k]), fill_team, {})
                 # the kernel is still running: its record and its stream are retired (it will write the record when it
                 # ends; the stream's later searches would queue behind it)
-                dsearch["retired"].append((rec, dsearch["streams"][i % len(dsearch["streams"])]))
+                _abandon((rec, dsearch["streams"][i % len(dsearch["streams"])]))
                 dsearch["recs"][b] = dev.new_search_record()
                 dsearch["streams"][i % len(dsearch["streams"])] = dev.replacement_search_stream(x0.device, eng["search_streams"])
                 return p0, p1, k, int(opt.nfev), float(opt.fun), {"generations_ms": 1e3 * opt.get("t_generations", 0.0),
@@ -987,6 +995,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                         _lib.call("xm_hostsearch_submit", sel[j % ring].h_slice.data_ptr(), n, plan.extra["freq_c"].ctypes.data,
                                   aps.METHODS.index(method), k, int(iw), int(bool(p0_only)), 42, 0.01, 1000, int(th), seq, rec.data_ptr())
 
+                    _abandon(rec)  # (the late search writes it whenever it ends, maybe after this call has returned)
                     tm = threading.Timer(slow_ms * 1e-3, late)
                     tm.daemon = True
                     tm.start()
