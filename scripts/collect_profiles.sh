@@ -60,6 +60,11 @@ fi
 if has labs; then
   python3 scripts/time_guess_stage.py > $out/guess_stage.txt 2>/dev/null
   NSETS=12 python3 scripts/time_hetero.py > $out/hetero_steps.txt 2>/dev/null
+  { echo "== heterogeneous family, 16 datasets per call (13 of 16 searches need the reference-route polish): ms per dataset";
+    echo "-- default: polish in worker processes"; NSETS=16 python3 scripts/time_hetero.py 2>/dev/null | grep "^rep";
+    echo "-- XM_POLISH_THREADS=2: polish on helper threads of the launch process"; XM_POLISH_THREADS=2 NSETS=16 python3 scripts/time_hetero.py 2>/dev/null | grep "^rep";
+    echo "-- XMRIS_AMD_POLISH=native: round 3's native polish"; XMRIS_AMD_POLISH=native NSETS=16 python3 scripts/time_hetero.py 2>/dev/null | grep "^rep";
+  } > $out/hetero_polish.txt
   python3 scripts/time_accessor_host_path.py > $out/host_path.txt 2>/dev/null
   python3 scripts/c1_tolerance.py > $out/c1_tolerance.txt 2>/dev/null
   python3 scripts/check_device_search.py > $out/device_search.txt 2>/dev/null || true   # (two degenerate slices diverge: exit 1)

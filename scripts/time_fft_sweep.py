@@ -3,7 +3,7 @@ ms per call and GB/s of compulsory traffic (read + write once) on ~2 GiB (c64) /
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xmris_amd import device as dev
-lengths = [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 16384, 1531, 4093, 1000, 6000]
+lengths = [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 16384, 768, 1531, 1972, 2000, 4093, 1000, 6000]
 for dt, B in ((torch.complex64, 8), (torch.complex128, 16)):
     for n in lengths:
         if not dev.fft_supported(n, dt == torch.complex128):
@@ -15,7 +15,9 @@ for dt, B in ((torch.complex64, 8), (torch.complex128, 16)):
         torch.cuda.synchronize(); ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); y = f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+            y = f(); e0.record()
+            for _ in range(4): y = f()  # (back to back: the device's time per call, not the wrapper's)
+            e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 4)
         ms = float(np.median(ts))
         print(f"{str(dt):18s} n={n:6d} batch={nb:7d}  {ms:8.4f} ms  {2*nb*n*B/ms/1e6:8.1f} GB/s")
         del x, y

@@ -51,6 +51,14 @@
   X(2560, 128, 4, 4, 4, 2, 20) \
   X(5120, 256, 4, 4, 4, 4, 20)
 
+// 1536 on ONE wave per spectrum pair, 24 points per thread, three stages instead of five -- for the plain transform
+// (the staged to_spectrum seam, complex64): same-box A/B against the row above 4.83 -> 5.13-5.16 TB/s.  The fused modes
+// keep the 12-point plan: with the ramp, the maxima and the prefetch the 24-point kernel needs ~460 VGPRs and the
+// configs[4] main pass LOSES 5 % (0.165 -> 0.174 ms).  The same idea loses on 768 (32 threads: 5.1 -> 3.7 TB/s) and
+// 3072 (128 threads x 24 points: 4.6 -> 3.1 odd factor first, 4.3 last).  profiles/r04/ab_plans.txt
+struct Plan1536Wide {
+  using type = FftPlan<1536, 64, 8, 8, 24>;
+};
 // 16384, complex64: 128 KiB of exchange buffer
 #define XM_PLANS_C64_ONLY(X) X(16384, 1024, 16, 16, 16, 4)
 // 16384, complex128: 16384 x 16 B does not fit the 160 KiB LDS -- the exchange goes through one plane of doubles,
