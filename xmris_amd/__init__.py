@@ -5,7 +5,7 @@ reference's accessor method names.  Hand-written HIP kernels reached through a C
 (`include/xmris_hip.h`, `xmris_amd/libxmris_hip.so`); Python keeps dims / coords / attrs.
 """
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"
 
 from . import _lib  # noqa: F401
 from .accessor import XmrisAccessor, register_xarray_accessor

@@ -15,7 +15,7 @@
 #include <mutex>
 #include <tuple>
 
-#define XM_VERSION_NUM 301  // 0.3.1 (round 3: xm_guess_*, xm_pipeline_key_native, XM_KEY_BYTES 131072; xm_solver_fg, xm_solver_pool_backups)
+#define XM_VERSION_NUM 400  // 0.4.0 (round 4: xm_search_*, xm_hostsearch_*, xm_stream_*, xm_zf_apod, xm_atomic_*, xm_last_kernel_string)
 
 static thread_local std::string g_err;
 static thread_local std::string g_last_kernel;

@@ -41,6 +41,7 @@ struct Service {
   std::deque<Job> queue;
   std::vector<std::thread> workers;
   int idle = 0;
+  int running = 0;      // searches being run right now
   int max_workers = 4;  // searches running at once (xm_hostsearch_set_workers); more submissions wait in the queue
   bool quit = false;
 
@@ -104,15 +105,23 @@ struct Service {
       {
         std::unique_lock<std::mutex> lk(mu);
         ++idle;
-        cv.wait(lk, [&] { return quit || !queue.empty(); });
+        // (the cap holds for the workers that exist, too: a hedged second start raises it for one submission and the
+        // thread it brought stays)
+        cv.wait(lk, [&] { return quit || (!queue.empty() && running < max_workers); });
         --idle;
         if (quit) return;
         j = std::move(queue.front());
         queue.pop_front();
+        ++running;
       }
       j.slice = j.slice_copy.data();
       j.coords = j.coords_copy.data();
       run_job(j);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        --running;
+      }
+      cv.notify_one();  // (a job may have been waiting for this slot)
     }
   }
 };
@@ -161,7 +170,7 @@ int xm_hostsearch_submit(const void* slice, int n, const double* coords, int met
   return XM_OK;
 }
 
-// searches the service runs side by side (1 ... 8; default 4); returns the value set.  Workers already started stay.
+// searches the service runs side by side (1 ... 8; default 4); returns the value set.
 int xm_hostsearch_set_workers(int n) {
   Service* s;
   {
@@ -169,9 +178,13 @@ int xm_hostsearch_set_workers(int n) {
     if (!g_service) g_service = new Service();
     s = g_service;
   }
-  std::lock_guard<std::mutex> lk(s->mu);
-  s->max_workers = n < 1 ? 1 : (n > 8 ? 8 : n);
-  return s->max_workers;
+  int v;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    v = s->max_workers = n < 1 ? 1 : (n > 8 ? 8 : n);
+  }
+  s->cv.notify_all();  // (a raised cap may let queued jobs start)
+  return v;
 }
 
 }  // extern "C"
