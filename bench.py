@@ -365,6 +365,9 @@ def main():
                 spec_stats[r.speculation] = spec_stats.get(r.speculation, 0) + (1 if record else 0)
                 if getattr(r, "hedged", False) and record:
                     spec_stats["hedged"] = spec_stats.get("hedged", 0) + 1
+                if record and r.mine and isinstance(getattr(r, "timing", None), dict):  # which engine searched it
+                    eng_key = "searches_device" if r.timing.get("device") else "searches_host"
+                    spec_stats[eng_key] = spec_stats.get(eng_key, 0) + 1
         res = results[-1]
         last.update(p0=res.p0, p1=res.p1, pivot=res.pivot, flat=res.flat_index, owner=res.owner)
         for r in results:
@@ -480,6 +483,11 @@ def main():
                                ("search_done_to_collect_ms", "t_search_end", "t_collect"), ("collect_to_solved_ms", "t_collect", "t_solved")):
                 print(name, [round((e[b] - e[a]) * 1e3, 3) if a in e and b in e else None for e in timed_trace], file=sys.stderr)
             print("t_collect_ms", [round((e["t_collect"] - t0) * 1e3, 2) for e in timed_trace if "t_collect" in e], file=sys.stderr)
+        if timed_trace and "t_selected" in timed_trace[-1]:  # one line per rank: where the launch thread was when (ms)
+            t0 = timed_trace[0]["t_start"]
+            marks = ("t_start", "t_selected", "t_exchanged", "t_collect", "t_solved")
+            print(f"[rank {rank}] timeline (start, selected, exchanged, collect, solved) " + " | ".join(
+                " ".join(f"{(e[m] - t0) * 1e3:.1f}" if m in e else "-" for m in marks) for e in timed_trace), file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nv * args.steps / elapsed
     main_ms = float(np.mean(times["main_ms"]))
@@ -545,7 +553,9 @@ def main():
                       "pre-pass of step i+1 overlaps the host solve of step i (independent datasets)") if overlap
                      else "strictly serial steps"),
         "speculation": ({"enabled": True, "hit": spec_stats.get("hit", 0), "repaired": spec_stats.get("repaired", 0),
-                         "searches_started_twice": spec_stats.get("hedged", 0)}
+                         "searches_started_twice": spec_stats.get("hedged", 0),
+                         "searches_host_engine": spec_stats.get("searches_host", 0),
+                         "searches_device_engine": spec_stats.get("searches_device", 0)}
                         if speculate else {"enabled": False}),
         "prime_ms": args.prime_ms,
         "prime_ms_spent": round(prime_spent_ms, 1),
@@ -560,7 +570,8 @@ def main():
                     "searches_owned": len(times["gen_ms"]),
                     "search_generations_mean_ms": float(np.mean(times["gen_ms"])) if times["gen_ms"] else None,
                     "main_kernel_ms": main_ms, "host_cores_used": cpu_cores, "ms_per_step_local": ms_per_step,
-                    "hedged": spec_stats.get("hedged", 0), "repaired": spec_stats.get("repaired", 0)}
+                    "hedged": spec_stats.get("hedged", 0), "repaired": spec_stats.get("repaired", 0),
+                    "searches_device_engine": spec_stats.get("searches_device", 0)}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine_rec, group=host_group)
         result["per_rank"] = gathered

@@ -495,11 +495,18 @@ def _run_stream_speculative(inputs, outputs, plan, exchange, broadcast, rank_off
     # streaming kernels lose more than the CUs' share (65,536 x 4096 -> 8192: 52.3 vs 48.0 M spectra/s; 16,384 x 2048
     # -> 4096: 0.35 vs 0.49 ms per dataset).  What the device engine buys is independence from the host: 2 instead of
     # 6 busy cores, and a schedule that a contended or core-starved host cannot disturb.  "auto" therefore takes it
-    # only where the host cannot carry the searches: fewer than three CPUs per rank of this node.
+    # only where the host cannot carry the searches: fewer than TWO CPUs per rank of this node (searches are per
+    # dataset, not per rank: eight ranks on 16 CPUs still carry them -- one core per launch thread, eight for the
+    # teams, profiles/r03/rehearsal_6ranks.txt).
     want = os.environ.get("XMRIS_AMD_SEARCH", "auto")
     if want == "auto":
         local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-        want = "device" if aps._cpu_share() < 3 * local_world else "host"
+        # ... and only where every rank has a GPU of its own: the partition is made of CU-masked queues, and those of
+        # several processes on ONE card reserve the same CUs and oversubscribe its hardware queues -- six ranks sharing
+        # a GPU fell into the scheduler's 10.7 ms process time slices, 124 instead of 1.4 ms per step
+        # (profiles/r04/rehearsal_6ranks.txt; four ranks still ran at full speed)
+        own_gpu = torch.cuda.device_count() >= local_world
+        want = "device" if (aps._cpu_share() < 2 * local_world and own_gpu) else "host"
     use_dev = (want == "device" and polish == "exact" and method == "acme"
                and overlap and axis is not False and dev.search_supported(n, method, axis[2]))
     dev_ahead = 0
@@ -965,6 +972,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             pending[j] = (None, ("dev", dev_seq.pop(j)), None)
             return
         amax, flat, sl = sel[j % ring].wait()  # (largest L1 norm, guessed row * n + arg-max of its fp64 spectrum, spectrum)
+        ev["t_selected"] = time.perf_counter()
         gflat, mine, owner = rank_offset_rows * n + flat, True, 0
         if exchange is not None:  # the guess is global too: the rank with the largest norm owns it
             mine, gflat, owner = exchange(amax, gflat)
