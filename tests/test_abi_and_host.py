@@ -521,6 +521,52 @@ def test_lean_polish_is_scipys_minimize_to_the_bit(oracle, monkeypatch, fg):
     assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev
 
 
+def test_polish_workers_never_make_a_caller_wait_for_their_start(oracle):
+    """`autophase_solver.PolishWorkers`: a request submitted before any worker has reported ready is polished by the
+    future's own thread; once the workers are up they answer with the same (x, fun, nfev) to the bit -- the polish is
+    the reference's route either way (phasing.py:276-284 with scipy's defaults) -- and a worker that dies is replaced by
+    the in-thread polish, not waited for."""
+    import time
+
+    from xmris_amd import autophase_solver as aps
+
+    rng = np.random.default_rng(11)
+    nt = 512
+    t = np.arange(nt) / 5000.0
+    x = sum(a * np.exp(-d * t) * np.exp(2j * np.pi * f * t + 1j * ph) for a, d, f, ph in
+            ((1.0, 25.0, 310.0, 0.4), (0.6, 40.0, -900.0, -1.1)))
+    x = (x + 0.05 * (rng.standard_normal(nt) + 1j * rng.standard_normal(nt)))[None, :]
+    _, inf = oracle.pipeline_values(x, t, 2 * nt, 5.0, solve=False)
+    sl, fr, pv, ti = inf["slice"], inf["freq"], inf["pivot"], inf["target_idx"]
+    args = (sl, fr, pv, ti, aps.index_width_of(fr, 100), "acme", False, np.array([12.0, 150.0]))
+    want = aps.polish_reference(*args)
+
+    def same(got):
+        return np.array_equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2]
+
+    pw = aps.PolishWorkers(2, lazy=True)
+    try:
+        assert not pw._started and pw._free.qsize() == 0
+        t0 = time.perf_counter()
+        assert same(pw.submit(*args).result(timeout=60))  # starts the children, is answered without them
+        first = time.perf_counter() - t0
+        assert pw._started
+        deadline = time.time() + 120
+        while pw._free.qsize() < 2 and time.time() < deadline:
+            time.sleep(0.05)
+        assert pw._free.qsize() == 2, "the workers did not report ready"
+        futs = [pw.submit(*args) for _ in range(6)]
+        assert all(same(f.result(timeout=60)) for f in futs)
+        assert pw._free.qsize() == 2  # both back on the free list
+        pw._procs[0].kill()
+        pw._procs[0].wait()
+        futs = [pw.submit(*args) for _ in range(4)]
+        assert all(same(f.result(timeout=60)) for f in futs)
+        assert first < 30.0
+    finally:
+        pw.close()
+
+
 @pytest.mark.parametrize("breakage", ["module_gone", "other_signature", "other_release"])
 def test_polish_falls_back_to_public_minimize_when_scipy_internals_change(oracle, monkeypatch, breakage):
     """`polish_lbfgsb` follows a PRIVATE entry point of scipy 1.15 (`scipy.optimize._lbfgsb.setulb`); the reference's

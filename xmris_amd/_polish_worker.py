@@ -22,6 +22,8 @@ def main():
         pass
     inp, out = sys.stdin.buffer, sys.stdout.buffer
     sys.stdout = sys.stderr  # (anything a library prints must not end up in the reply stream)
+    out.write(b"XMREADY\n")  # (eight bytes: the parent hands requests only to workers that have said this)
+    out.flush()
     while True:
         head = inp.read(8)
         if len(head) < 8:

@@ -440,46 +440,77 @@ def polish_reference(sl, coords, pivot, target_idx, index_width, method, p0_only
 class PolishWorkers:
     """A few worker PROCESSES (`xmris_amd/_polish_worker.py`, started as plain children: `python -c ...`, no fork of
     this process, no re-import of its main module) that run `polish_reference` away from this process's interpreter
-    lock.  `submit(...)` takes `polish_reference`'s arguments and returns a future; a worker that cannot be started or
-    dies mid-request makes the future's thread do the polish itself."""
+    lock.  `submit(...)` takes `polish_reference`'s arguments and returns a future.  Nobody ever waits for a worker to
+    come up: a worker joins the free list when it has reported ready (its imports take ~1 s of CPU), and a request that
+    finds no free worker -- none started yet, all busy, one died -- is polished by the future's own thread.
+    `start()` launches the children (idempotent); with `lazy` the first request does (several ranks on one node: 6 x 4
+    interpreters importing scipy at the start of a stream ate a 16-CPU quota and the cgroup was throttled for
+    40-60 ms inside the timed region, profiles/r04/rehearsal_6ranks.txt)."""
 
-    def __init__(self, n: int = 4):
-        import os
+    def __init__(self, n: int = 4, lazy: bool = False):
         import queue
-        import subprocess
-        import sys
+        import threading
         from concurrent.futures import ThreadPoolExecutor
 
+        self._n = max(1, int(n))
         self._free = queue.Queue()
         self._procs = []
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
-                   OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        for _ in range(max(1, n)):
-            try:
-                pr = subprocess.Popen([sys.executable, "-c", "from xmris_amd import _polish_worker as w; w.main()"],
-                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
-            except OSError:
-                break
-            self._procs.append(pr)
-            self._free.put(pr)
-        # (threads that only wait on a pipe: they hold the interpreter lock for microseconds per request)
-        self._pool = ThreadPoolExecutor(max_workers=max(1, len(self._procs)), thread_name_prefix="xm-polish")
+        self._started = False
+        self._lock = threading.Lock()
+        # (threads that mostly wait on a pipe: they hold the interpreter lock for microseconds per request)
+        self._pool = ThreadPoolExecutor(max_workers=self._n, thread_name_prefix="xm-polish")
         import atexit
 
         atexit.register(self.close)
+        if not lazy:
+            self.start()
+
+    def start(self):
+        import os
+        import subprocess
+        import sys
+        import threading
+
+        with self._lock:
+            if self._started:
+                return
+            self._started = True
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
+                       OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            for _ in range(self._n):
+                try:
+                    pr = subprocess.Popen([sys.executable, "-c", "from xmris_amd import _polish_worker as w; w.main()"],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
+                except OSError:
+                    break
+                self._procs.append(pr)
+                threading.Thread(target=self._await_ready, args=(pr,), daemon=True, name="xm-polish-ready").start()
+
+    def _await_ready(self, pr):
+        try:
+            if pr.stdout.read(8) == b"XMREADY\n":  # (written by the worker once numpy, scipy and the objective are imported)
+                self._free.put(pr)
+        except Exception:  # noqa: BLE001 -- a worker that never reports is never used
+            pass
 
     def submit(self, *args):
+        if not self._started:
+            self.start()
         return self._pool.submit(self._call, args)
 
     def _call(self, args):
         import pickle
+        import queue
         import struct
 
         pr = None
         try:
-            pr = self._free.get(timeout=60.0) if self._procs else None
-            if pr is not None and pr.poll() is None:
+            pr = self._free.get_nowait()
+        except queue.Empty:
+            return polish_reference(*args)
+        try:
+            if pr.poll() is None:
                 blob = pickle.dumps(args, protocol=pickle.HIGHEST_PROTOCOL)
                 pr.stdin.write(struct.pack("<q", len(blob)))
                 pr.stdin.write(blob)
@@ -492,7 +523,7 @@ class PolishWorkers:
         except Exception:  # noqa: BLE001 -- any trouble with a worker: this thread does the polish
             pass
         finally:
-            if pr is not None and pr.poll() is None:
+            if pr.poll() is None:
                 self._free.put(pr)
         return polish_reference(*args)
 
@@ -518,12 +549,16 @@ _POLISH_WORKERS = None
 
 
 def polish_workers():
-    """The process-wide `PolishWorkers` (created on first use; `XM_POLISH_WORKERS` = how many, default 4)."""
+    """The process-wide `PolishWorkers`, created on first use.  How many (`XM_POLISH_WORKERS`): up to four, and at most
+    one per two CPUs of this rank's share; one rank alone starts them at once, several ranks on a node start theirs
+    with the first search that needs a polish."""
     import os
 
     global _POLISH_WORKERS
     if _POLISH_WORKERS is None:
-        _POLISH_WORKERS = PolishWorkers(int(os.environ.get("XM_POLISH_WORKERS", "4")))
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        n = int(os.environ.get("XM_POLISH_WORKERS", "0")) or max(1, min(4, _cpu_share() // (2 * local_world)))
+        _POLISH_WORKERS = PolishWorkers(n, lazy=local_world > 1)
     return _POLISH_WORKERS
 
 
