@@ -486,8 +486,9 @@ def main():
         if timed_trace and "t_selected" in timed_trace[-1]:  # one line per rank: where the launch thread was when (ms)
             t0 = timed_trace[0]["t_start"]
             marks = ("t_start", "t_selected", "t_exchanged", "t_collect", "t_solved")
-            print(f"[rank {rank}] timeline (start, selected, exchanged, collect, solved) " + " | ".join(
-                " ".join(f"{(e[m] - t0) * 1e3:.1f}" if m in e else "-" for m in marks) for e in timed_trace), file=sys.stderr)
+            sys.stderr.flush()
+            os.write(2, (f"\n[rank {rank}] timeline (start, selected, exchanged, collect, solved) " + " | ".join(
+                " ".join(f"{(e[m] - t0) * 1e3:.1f}" if m in e else "-" for m in marks) for e in timed_trace) + " |\n").encode())  # (one write: the ranks share stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nv * args.steps / elapsed
     main_ms = float(np.mean(times["main_ms"]))

@@ -8,13 +8,14 @@ import sys
 THRESH = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 ranks = {}
 for line in sys.stdin:
-    m = re.match(r"\[rank (\d+)\] timeline \([^)]*\) (.*)", line)
+    m = re.search(r"\[rank (\d+)\] timeline \([^)]*\) (.*)", line)
     if not m:
         continue
     sets = []
-    for part in m.group(2).split(" | "):
-        vals = part.split()[:5]
-        sets.append([float(v) if v != "-" else float("nan") for v in vals])
+    for part in m.group(2).split(" |"):
+        vals = re.findall(r"-?\d+\.\d|(?<![\d.])-(?![\d.])", part)[:5]
+        if len(vals) == 5:
+            sets.append([float(v) if v != "-" else float("nan") for v in vals])
     ranks[int(m.group(1))] = sets
 n = min(len(v) for v in ranks.values())
 for j in range(n):
@@ -24,5 +25,5 @@ for j in range(n):
         for name, d in (("sel", sel - st), ("exch", ex - sel), ("solve", sol - col)):
             if d > THRESH:
                 notes.append(f"r{r} {name} {d:.1f}")
-    t = ranks[0][j]
+    t = ranks[min(ranks)][j]
     print(f"set {j:2d}  start {t[0]:8.1f}  solved {t[4]:8.1f}  " + ("; ".join(notes) if notes else "-"))

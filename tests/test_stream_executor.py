@@ -110,6 +110,34 @@ def test_speculative_executor_equals_classic_single_process(monkeypatch):
         assert _stream_double.COUNTS["guess_rows"] == N_SETS and _stream_double.COUNTS["main"] == 2 * (N_SETS + len(MISSES))
 
 
+@pytest.mark.parametrize("cpus,ranks,gpus,want_device", [(16, 1, 1, False), (1, 1, 1, True), (16, 6, 1, False), (8, 6, 1, False),
+                                                        (8, 8, 8, True), (16, 8, 8, False), (128, 8, 8, False)])
+def test_auto_engine_rule(monkeypatch, cpus, ranks, gpus, want_device):
+    """`XMRIS_AMD_SEARCH=auto`: the device-resident search only where a rank has a GPU of its own AND fewer than two
+    CPUs -- the six-rank rehearsal on one card (16 CPUs) had picked it and ran 100 x slower (CU-masked queues of six
+    processes on one GPU), profiles/r04/rehearsal_6ranks.txt."""
+    import _stream_double
+
+    _stream_double.install(monkeypatch)
+    import torch
+
+    from xmris_amd import autophase_solver as aps
+    from xmris_amd import pipeline as pl
+
+    monkeypatch.setenv("XM_SOLVER_THREADS", "2")
+    monkeypatch.delenv("XMRIS_AMD_SEARCH", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+    monkeypatch.setattr(aps, "_CPU_SHARE", cpus)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: gpus)
+    for k in _stream_double.COUNTS:
+        _stream_double.COUNTS[k] = 0
+    plan = _plan(pl, torch)
+    ins = [torch.from_numpy(make_dataset(d, 1)) for d in range(N_SETS)]
+    outs = [torch.empty((ins[0].shape[0], N_OUT), dtype=torch.complex128) for _ in range(N_SETS)]
+    pl.run_stream(ins, outs, plan, speculate=True)  # (one process: `exchange` is None, LOCAL_WORLD_SIZE only feeds the rule)
+    assert (_stream_double.COUNTS["search_launch"] > 0) == want_device
+
+
 def _rank_main(rank, world, port, engine, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_WORLD_SIZE=str(world), XM_SOLVER_THREADS="1", XMRIS_AMD_SEARCH=engine,
