@@ -226,8 +226,14 @@ bool xm_zf2p_eligible(const PipeArgs<float>& A, int64_t in_stride) {
 int xm_zf2p_launch(int h, const PipeArgs<float>& A, const double* ramp, hipStream_t st) {
   switch (h) {
     case 512: return launch_plan<typename Zf2PlanOf<512>::type>(A, ramp, st);
+#ifdef XM_ZF2P_WIDE_SMALL  // build-time A/B switch: the 16-point plans (fewer stages, half the threads) below 4096 too --
+                          // round 4, same box: configs[1] main pass 0.1721 vs 0.1724 ms, maxima-only pass 0.113 vs 0.107: left off
+    case 1024: return launch_plan<typename PlanOf<1024>::type>(A, ramp, st);
+    case 2048: return launch_plan<typename PlanOf<2048>::type>(A, ramp, st);
+#else
     case 1024: return launch_plan<typename Zf2PlanOf<1024>::type>(A, ramp, st);
     case 2048: return launch_plan<typename Zf2PlanOf<2048>::type>(A, ramp, st);
+#endif
     case 4096: return launch_plan<typename PlanOf<4096>::type>(A, ramp, st);  // 256 threads x 16 points, 16.16.16
     case 8192: return launch_plan<typename Zf2PlanOf<8192>::type>(A, ramp, st);  // 1024 x 8, one workgroup per CU
     default: break;
