@@ -814,7 +814,24 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             polish_futs.pop(i, None)
         return p0, (p1 if not p0_only else 0.0), nfev, fun, timing, hedged
 
-    def guess(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
+    # (tuning switch XM_GUESS_STREAM=1: the guess + selection chain on a stream of its own beside the main passes.
+    # Round 3 measured it on the roofline shape: -7 %, the coarse-spectra kernel fills the chip and the main kernel
+    # slows down beside it; round 4 on the small shapes, whose 0.17 ms main passes leave ramp-up and tail bubbles:
+    # profiles/r04/guess_stream.txt.)
+    guess_stream = None
+    if os.environ.get("XM_GUESS_STREAM", "0") not in ("", "0") and torch.cuda.is_available():
+        guess_stream = plan.extra.get("guess_stream")
+        if guess_stream is None:
+            guess_stream = plan.extra["guess_stream"] = torch.cuda.Stream(device=x0.device)
+        guess_stream.wait_stream(torch.cuda.current_stream(x0.device))  # (the inputs are ready on the caller's stream)
+
+    def guess(j):
+        if guess_stream is None:
+            return guess_on_current_stream(j)
+        with torch.cuda.stream(guess_stream):
+            return guess_on_current_stream(j)
+
+    def guess_on_current_stream(j):  # coarse spectra (or streaming L1 norms) + the selection stage on the winning row
         b = j % ring
         ev = events[j]
         if trace is not None:
