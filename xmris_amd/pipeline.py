@@ -1078,6 +1078,19 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
 
     guessed = started = -1
     unverified = []  # datasets whose main pass is queued and whose guess is not settled yet (ascending)
+    # (the order of the exchange calls must be the same on every rank: with several ranks the fill keeps its fixed order)
+    fast_fill = (exchange is None and not use_dev and overlap and n_sets > 2 and s_ahead >= 2
+                 and os.environ.get("XM_FAST_FILL", "1") != "0")
+
+    # (tuning switch, off: measured with four and six ranks sharing the box's one GPU -- 1.61 vs 1.59 and 1.38 vs
+    # 1.40 ms per step, nothing either way; untested where every rank has its own GPU)
+    fill_ramp = overlap and os.environ.get("XM_FILL_RAMP", "0") != "0"
+
+    def first_search_done():
+        _, fut0, _ = pending[0]
+        if isinstance(fut0, tuple) and len(fut0) == 2 and fut0[0] == "host":
+            return dev.search_done(hsearch["recs"][0], fut0[1])
+        return fut0 is None or not hasattr(fut0, "done") or fut0.done()
     for i in range(n_sets):
         b = i % ring
         ev = events[i]
@@ -1086,7 +1099,32 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         # (device engine: a search is started as soon as its selection stage is queued -- one rank -- or has ended --
         # several ranks, whose exchange needs the stage's result: one dataset behind the newest guess)
         s_look = s_ahead if not use_dev else (g_ahead if exchange is None else max(s_ahead, g_ahead - 1))
-        while started < min(n_sets - 1, i + s_look):
+        if i == 0 and fast_fill:
+            # Filling the pipeline, one rank: every guess of the look-ahead is queued at once (the device works through
+            # them while the first search runs), searches start as their selection stages END -- this thread polls the
+            # events instead of blocking on each in turn -- and the moment the FIRST search is there its main pass is
+            # queued.  Starting all the look-ahead's searches first, each behind a blocking wait for its selection
+            # (8 x (0.13 ms of kernels + the host's turnaround)), had the first main pass queued at 1.5-1.7 ms with
+            # the first search done at 1.0 and the device idle in between (profiles/r04/fill.txt).
+            while guessed < min(n_sets - 1, g_ahead):
+                guessed += 1
+                guess(guessed)
+            started = 0
+            start_search(0)
+            while not first_search_done():
+                nxt = started + 1
+                if nxt > min(n_sets - 1, s_look) or nxt > guessed:
+                    break  # (the look-ahead is full: `collect` waits for the first search -- and hedges it if it is late)
+                if sel[nxt % ring].event.query():
+                    started = nxt
+                    start_search(nxt)
+                elif blocking:
+                    time.sleep(2e-5)
+        # (several ranks -- where the order of the exchange calls may not depend on anything a rank observes -- and the
+        # other engines: the look-ahead is built up over the first datasets, three searches before the first main pass
+        # and three more with every dataset, instead of all of it in front of the first main pass)
+        ramp = 2 + 3 * i if (not use_dev and not fast_fill and fill_ramp) else n_sets
+        while started < min(n_sets - 1, i + s_look, ramp):
             while guessed < min(n_sets - 1, started + 1):
                 guessed += 1
                 guess(guessed)
