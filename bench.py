@@ -486,6 +486,11 @@ def main():
         if timed_trace and "t_selected" in timed_trace[-1]:  # one line per rank: where the launch thread was when (ms)
             t0 = timed_trace[0]["t_start"]
             marks = ("t_start", "t_selected", "t_exchanged", "t_collect", "t_solved")
+            if "t_call" in timed_trace[0]:
+                tc, last = timed_trace[0]["t_call"], timed_trace[-1]
+                print(f"[rank {rank}] timed region {elapsed * 1e3:.2f} ms: executor entered at {(tc - t_start) * 1e3:.2f}, first search "
+                      f"started at {(t0 - t_start) * 1e3:.2f}, last main pass queued at {(last.get('t_last_queued', tc) - t_start) * 1e3:.2f}, "
+                      f"executor returned at {(last.get('t_return', tc) - t_start) * 1e3:.2f}", file=sys.stderr)
             sys.stderr.flush()
             os.write(2, (f"\n[rank {rank}] timeline (start, selected, exchanged, collect, solved) " + " | ".join(
                 " ".join(f"{(e[m] - t0) * 1e3:.1f}" if m in e else "-" for m in marks) for e in timed_trace) + " |\n").encode())  # (one write: the ranks share stderr)

@@ -567,6 +567,8 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     """The software pipeline of `_run_stream_speculative` (engine and look-ahead chosen there)."""
     import os
     import time
+
+    t_call = time.perf_counter()
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
@@ -1077,6 +1079,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         res.speculation = "repaired"
 
     guessed = started = -1
+    events[0]["t_call"] = t_call
     unverified = []  # datasets whose main pass is queued and whose guess is not settled yet (ascending)
     # (the order of the exchange calls must be the same on every rank: with several ranks the fill keeps its fixed order)
     fast_fill = (exchange is None and not use_dev and overlap and n_sets > 2 and s_ahead >= 2
@@ -1085,6 +1088,10 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     # (tuning switch, off: measured with four and six ranks sharing the box's one GPU -- 1.61 vs 1.59 and 1.38 vs
     # 1.40 ms per step, nothing either way; untested where every rank has its own GPU)
     fill_ramp = overlap and os.environ.get("XM_FILL_RAMP", "0") != "0"
+
+    # searches started beside the pipeline-filling one (it has the whole team for its millisecond; the others have
+    # device periods of slack and start right behind it) -- tuning switch, A/B in profiles/r04/fill.txt
+    fill_searches = int(os.environ.get("XM_FILL_SEARCHES", "1"))
 
     def first_search_done():
         _, fut0, _ = pending[0]
@@ -1106,19 +1113,25 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             # queued.  Starting all the look-ahead's searches first, each behind a blocking wait for its selection
             # (8 x (0.13 ms of kernels + the host's turnaround)), had the first main pass queued at 1.5-1.7 ms with
             # the first search done at 1.0 and the device idle in between (profiles/r04/fill.txt).
-            while guessed < min(n_sets - 1, g_ahead):
+            while guessed < min(n_sets - 1, 1):  # (two guesses, then the first search: nothing else delays its start)
                 guessed += 1
                 guess(guessed)
             started = 0
             start_search(0)
             while not first_search_done():
+                more_guesses = guessed < min(n_sets - 1, g_ahead)
+                if more_guesses:  # one per turn: a launch takes this thread half the time the device needs for it
+                    guessed += 1
+                    guess(guessed)
                 nxt = started + 1
-                if nxt > min(n_sets - 1, s_look) or nxt > guessed:
-                    break  # (the look-ahead is full: `collect` waits for the first search -- and hedges it if it is late)
-                if sel[nxt % ring].event.query():
+                if nxt > min(n_sets - 1, s_look, fill_searches):
+                    if more_guesses:
+                        continue
+                    break  # (`collect` waits for the first search -- and hedges it if it is late)
+                if nxt <= guessed and sel[nxt % ring].event.query():
                     started = nxt
                     start_search(nxt)
-                elif blocking:
+                elif blocking and not more_guesses:
                     time.sleep(2e-5)
         # (several ranks -- where the order of the exchange calls may not depend on anything a rank observes -- and the
         # other engines: the look-ahead is built up over the first datasets, three searches before the first main pass
@@ -1186,8 +1199,10 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         unverified.append(i)
         if trace is not None:
             trace.append(ev)
+    events[-1]["t_last_queued"] = time.perf_counter()
     while unverified:
         verify(unverified.pop(0))
+    events[-1]["t_return"] = time.perf_counter()
     return results
 
 
