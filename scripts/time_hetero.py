@@ -21,6 +21,16 @@ plan = pipeline.make_plan(sets[0], t, N, 5.0)
 outs = [torch.empty((nv, N), dtype=dtype, device="cuda") for _ in range(2)]
 pipeline.run_stream(sets[:4], [outs[k % 2] for k in range(4)], plan, speculate=True)
 torch.cuda.synchronize()
+if not os.environ.get("XM_POLISH_THREADS") and os.environ.get("XMRIS_AMD_POLISH", "exact") == "exact":
+    # steady state: the polish workers are up (a stream started cold polishes in-process until they are, ~1 s)
+    from xmris_amd import autophase_solver as aps
+
+    pw = aps.polish_workers()
+    pw.start()
+    t_w = time.time()
+    while pw._alive < pw._n and time.time() - t_w < 30:
+        time.sleep(0.05)
+    print(f"polish workers ready: {pw._alive} of {pw._n} after {time.time() - t_w:.1f} s")
 for rep in range(2):
     trace = []
     t0 = time.perf_counter()

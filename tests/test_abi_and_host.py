@@ -563,6 +563,11 @@ def test_polish_workers_never_make_a_caller_wait_for_their_start(oracle):
         futs = [pw.submit(*args) for _ in range(4)]
         assert all(same(f.result(timeout=60)) for f in futs)
         assert first < 30.0
+        pw._procs[1].kill()  # ... and with the last one gone nobody waits for a worker any more
+        pw._procs[1].wait()
+        futs = [pw.submit(*args) for _ in range(3)]
+        assert all(same(f.result(timeout=60)) for f in futs)
+        assert pw._alive == 0 and pw._free.qsize() == 0
     finally:
         pw.close()
 

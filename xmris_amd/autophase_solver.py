@@ -453,6 +453,7 @@ class PolishWorkers:
         from concurrent.futures import ThreadPoolExecutor
 
         self._n = max(1, int(n))
+        self._alive = 0  # workers that have reported ready and have not been found dead
         self._free = queue.Queue()
         self._procs = []
         self._started = False
@@ -490,6 +491,8 @@ class PolishWorkers:
     def _await_ready(self, pr):
         try:
             if pr.stdout.read(8) == b"XMREADY\n":  # (written by the worker once numpy, scipy and the objective are imported)
+                with self._lock:
+                    self._alive += 1
                 self._free.put(pr)
         except Exception:  # noqa: BLE001 -- a worker that never reports is never used
             pass
@@ -504,11 +507,16 @@ class PolishWorkers:
         import queue
         import struct
 
+        # no worker is up (yet, or any more): this thread does it; otherwise wait for one to come free -- a polish in
+        # this process costs the launch thread its share of the interpreter lock, which is what the workers are for
         pr = None
-        try:
-            pr = self._free.get_nowait()
-        except queue.Empty:
-            return polish_reference(*args)
+        while pr is None:
+            if self._alive <= 0:
+                return polish_reference(*args)
+            try:
+                pr = self._free.get(timeout=0.02)
+            except queue.Empty:
+                pass
         try:
             if pr.poll() is None:
                 blob = pickle.dumps(args, protocol=pickle.HIGHEST_PROTOCOL)
@@ -525,6 +533,9 @@ class PolishWorkers:
         finally:
             if pr.poll() is None:
                 self._free.put(pr)
+            else:  # (found dead, before or during the request: it leaves the count, nobody waits for it again)
+                with self._lock:
+                    self._alive -= 1
         return polish_reference(*args)
 
     def close(self):
