@@ -4,6 +4,7 @@
 #include "xm_plans.h"
 #include "xm_tables.h"
 #include "xm_zf2p.h"
+#include "xm_coarse.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -182,6 +183,30 @@ int xm_zf2p_guess_rows(const void* in, int64_t in_stride, const float* window, i
   (void)n_out;
   int rc = half_table(A.n, &A.aux);
   if (rc) return rc;
+  // complex64 rows of at least 512 samples: the matrix-core version (xm_coarse.h); XM_GUESS_FFT=1 keeps the FFT one
+  static const bool fft_only = getenv("XM_GUESS_FFT") != nullptr;  // tuning switch
+  if (dtype == XM_C64 && ng == kGuessHalf && window && !fft_only) {
+    if (n_batch <= 0) return XM_OK;
+    CoarseArgs C;
+    C.in = (const Cx<float>*)in;
+    C.window = window;
+    C.w1024 = A.aux;
+    C.est = est;
+    C.gkey = key;
+    C.in_stride = in_stride;
+    C.n_batch = n_batch;
+    C.scale2 = scale * scale;
+    static XmResidency res;
+    int resident = 0;
+    rc = xm_resident_blocks(res, k_coarse_mfma, 64 * kCoarseWaves, 0, &resident, st);
+    if (rc) return rc;
+    const long long want = (n_batch + kCoarseWaves - 1) / kCoarseWaves;
+    const long long blocks = want < resident ? want : resident;
+    xm_note_kernel("k_coarse_mfma", nullptr, nullptr, kGuessHalf, -1);
+    hipLaunchKernelGGL(k_coarse_mfma, dim3((unsigned)blocks), dim3(64 * kCoarseWaves), 0, st, C);
+    HIP_TRY(hipGetLastError());
+    return XM_OK;
+  }
   using PL = typename Zf2PlanOf<kGuessHalf>::type;
   return dtype == XM_C64 ? launch_mode<PL, ZF2_AMAX, ZF2P_EST | ZF2P_LOAD16>(A, st)
                          : launch_mode<PL, ZF2_AMAX, ZF2P_EST | ZF2P_IN64>(A, st);
