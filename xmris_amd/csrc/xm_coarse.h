@@ -117,26 +117,46 @@ __global__ __launch_bounds__(64 * kCoarseWaves, 2) void k_coarse_mfma(CoarseArgs
   for (int j = 0; j < 8; ++j) wnd[j] = A.window[32u * (8u * h + (unsigned)j) + r];
 
   auto fetch = [&](long long s, Cx<float>* x) {
-    const Cx<float>* __restrict__ row = A.in + s * A.in_stride;
+    // (nontemporal: 256 MiB stream through once -- loaded the plain way they push the tables of the kernels that follow
+    // out of the L2: the one-workgroup fp64 transform of the selection stage went from 17 to 21 us)
+    const xm_f2* __restrict__ row = reinterpret_cast<const xm_f2*>(A.in + s * A.in_stride);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = row[32u * (8u * h + (unsigned)j) + r];
+    for (int j = 0; j < 8; ++j) {
+#if !defined(XM_COARSE_NT) || XM_COARSE_NT
+      const xm_f2 v = __builtin_nontemporal_load(row + 32u * (8u * h + (unsigned)j) + r);
+#else
+      const xm_f2 v = row[32u * (8u * h + (unsigned)j) + r];
+#endif
+      x[j] = mk<float>(v.x, v.y);
+    }
   };
 
   unsigned best_key = 0u, best_row = 0u;
   bool have = false;
-  Cx<float> nx[8];
+  // rows loaded ahead of the one being transformed (XM_COARSE_DEPTH, XM_COARSE_NT: compile-time A/B switches).
+  // Standalone on 65,536 rows, three rounds (profiles/r04/coarse_kernel.txt): depth 1 plain loads 56.6-57.4 us, depth 1
+  // nontemporal 60.0-60.8, depth 2 plain 58.4-58.6, depth 2 nontemporal 62.2-63.7 -- a second row in flight buys
+  // nothing (8 waves per CU already hold 32 KiB), and the nontemporal hint costs 4 us here but gives the kernels
+  // queued behind it their tables back (in the stream: refine 36.1 -> 33.7 us, the fp64 transform 21.2 -> 17.3).
+#ifndef XM_COARSE_DEPTH
+#define XM_COARSE_DEPTH 1
+#endif
+  constexpr int DEPTH = XM_COARSE_DEPTH;
+  Cx<float> nx[DEPTH][8];
   long long s = wave;
-  if (s < A.n_batch) fetch(s, nx);
-  for (; s < A.n_batch; s += n_waves) {
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (s + d * n_waves < A.n_batch) fetch(s + d * n_waves, nx[d]);
+  auto one_row = [&](Cx<float>* cur, long long s) {
     float re[8], im[8];
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      re[j] = nx[j].re * wnd[j];
-      im[j] = nx[j].im * wnd[j];
+      re[j] = cur[j].re * wnd[j];
+      im[j] = cur[j].im * wnd[j];
       m = fmaxf(m, fmaxf(fabsf(re[j]), fabsf(im[j])));  // (fmax drops NaNs: they reach the result through the products)
     }
-    if (s + n_waves < A.n_batch) fetch(s + n_waves, nx);
+    if (s + DEPTH * n_waves < A.n_batch) fetch(s + DEPTH * n_waves, cur);
     // power-of-two row scale: the largest sample into [1, 2)
     unsigned e = (wave_reduce_u32<true>(__float_as_uint(m)) >> 23) & 0xffu;
     e = e > 253u ? 253u : (e < 1u ? 1u : e);
@@ -180,6 +200,11 @@ __global__ __launch_bounds__(64 * kCoarseWaves, 2) void k_coarse_mfma(CoarseArgs
     best_row = take ? row : best_row;
     have = true;
     if (lane == 0u) A.est[s] = __uint_as_float(key);
+  };
+  for (; s < A.n_batch; s += DEPTH * n_waves) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (s + d * n_waves < A.n_batch) one_row(nx[d], s + d * n_waves);
   }
   if (A.gkey && have && lane == 0u)
     atomicMax(A.gkey + (blockIdx.x % XM_KEY_SLOTS) * XM_KEY_STRIDE,
