@@ -5,7 +5,7 @@ VARIANT:
   table = write + phase TABLE (k_zf2p mode 3; the first-generation kernel with XM_ZF2_GEN1=1)
   write = write only;  pre = arg-max pre-pass of the classic schedule
   guess = the sub-sampled windowed L1 norms (xm_row_l1 with an arg-max key) that replace the pre-pass (round 2)
-  coarse = the guess stage of round 3: xm_guess_rows (coarse spectra, k_zf2p<512-plan, 4, 17>) + xm_guess_refine
+  coarse = the guess stage: xm_guess_rows (coarse spectra: k_coarse_mfma, or k_zf2p<512-plan, 4, 17> with XM_GUESS_FFT=1) + xm_guess_refine
   rows  = write + phase ramp + per-row maxima (value only): the complex128 main pass of the speculative schedule
 DTYPE=c128 runs the complex128 kernels (`all`: k_zf2d with the arg-max key and the prefetch, mode 221)."""
 import sys, os, torch
