@@ -155,7 +155,7 @@ int xm_argmax_key_take(uint64_t* key, int n_per_row, void* out_max2, int64_t* ou
  *                    read) -- and the largest estimate in `key` (an arg-max key buffer, zero at launch).  A truncated,
  *                    coarsely sampled spectrum underestimates a line's height by a bounded factor (scalloping of the
  *                    grid, the missing tail), so the true arg-max row lies among the rows whose estimate is within
- *                    that band of the largest one.  XM_C64 rows of 512 samples and more are transformed on the matrix
+ *                    that band of the largest one.  Rows of 512 samples and more are transformed on the matrix
  *                    cores (fp16 operands behind a per-row power-of-two scale, fp32 sums: est within 2e-3 of the exact
  *                    coarse spectrum's maximum; a NaN sample gives NaN), other rows by the fp32 FFT (2e-5);
  *   xm_guess_refine  transforms every row with est[b] >= band^2 * max(est) exactly (all n_in samples -> n_out bins, the

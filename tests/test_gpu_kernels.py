@@ -497,9 +497,9 @@ def test_guess_rows_and_refine(dev, nb, n_in, n_out, dtype):
     m = min(512, n_in)
     xc = x[:, :m].astype(np.complex128) * w[:m]
     ref_est = (np.abs(np.fft.fft(xc, n=1024, axis=1)) ** 2).max(axis=1) / n_out
-    # complex64 rows of 512 samples and more take the matrix-core kernel (csrc/xm_coarse.h: fp16 operands behind a
-    # power-of-two row scale, fp32 sums): an ESTIMATE, good to 2e-3; the FFT kernel (short rows, complex128 rows) to 2e-5
-    mfma = dtype == "complex64" and n_in >= 512 and not os.environ.get("XM_GUESS_FFT")
+    # rows of 512 samples and more take the matrix-core kernel (csrc/xm_coarse.h: fp16 operands behind a power-of-two
+    # row scale, fp32 sums): an ESTIMATE, good to 2e-3; the FFT kernel (shorter rows) to 2e-5
+    mfma = n_in >= 512 and not os.environ.get("XM_GUESS_FFT")
     np.testing.assert_allclose(est.cpu().numpy(), ref_est, rtol=2e-3 if mfma else 2e-5)
     assert dev.last_kernel().startswith("k_coarse_mfma" if mfma else "k_zf2p")
     full = np.abs(np.fft.fft(x.astype(np.complex128) * w[:n_in], n=n_out, axis=1)) ** 2 / n_out

@@ -34,7 +34,7 @@ typedef _Float16 xm_h2 __attribute__((ext_vector_type(2)));
 typedef float xm_f16v __attribute__((ext_vector_type(16)));
 
 struct CoarseArgs {
-  const Cx<float>* in;       // [n_batch, in_stride] complex64 rows
+  const void* in;            // [n_batch, in_stride] complex64 (or complex128: IN64) rows
   const float* window;       // >= 512 weights
   const Cx<float>* w1024;    // W_1024^k, k < 512 (xm_gen_half(1024))
   float* est;                // [n_batch]
@@ -65,6 +65,7 @@ XM_DEV xm_h8 coarse_pack(const float* v) {  // eight floats -> eight halves, rou
   return u.v8;
 }
 
+template <bool IN64>  // complex128 rows: converted to float on load (a ranking statistic, like the FFT version's IN64 mode)
 __global__ __launch_bounds__(64 * kCoarseWaves, 2) void k_coarse_mfma(CoarseArgs A) {
   const unsigned lane = threadIdx.x & 63u, r = lane & 31u, h = lane >> 5;
   const long long wave = (long long)blockIdx.x * kCoarseWaves + (threadIdx.x >> 6);
@@ -119,7 +120,16 @@ __global__ __launch_bounds__(64 * kCoarseWaves, 2) void k_coarse_mfma(CoarseArgs
   auto fetch = [&](long long s, Cx<float>* x) {
     // (nontemporal: 256 MiB stream through once -- loaded the plain way they push the tables of the kernels that follow
     // out of the L2: the one-workgroup fp64 transform of the selection stage went from 17 to 21 us)
-    const xm_f2* __restrict__ row = reinterpret_cast<const xm_f2*>(A.in + s * A.in_stride);
+    if constexpr (IN64) {
+      const xm_d2* __restrict__ row = reinterpret_cast<const xm_d2*>(A.in) + s * A.in_stride;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const xm_d2 v = __builtin_nontemporal_load(row + 32u * (8u * h + (unsigned)j) + r);
+        x[j] = mk<float>((float)v.x, (float)v.y);
+      }
+      return;
+    }
+    const xm_f2* __restrict__ row = reinterpret_cast<const xm_f2*>(A.in) + s * A.in_stride;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #if !defined(XM_COARSE_NT) || XM_COARSE_NT

@@ -183,12 +183,12 @@ int xm_zf2p_guess_rows(const void* in, int64_t in_stride, const float* window, i
   (void)n_out;
   int rc = half_table(A.n, &A.aux);
   if (rc) return rc;
-  // complex64 rows of at least 512 samples: the matrix-core version (xm_coarse.h); XM_GUESS_FFT=1 keeps the FFT one
+  // rows of at least 512 samples: the matrix-core version (xm_coarse.h); XM_GUESS_FFT=1 keeps the FFT one
   static const bool fft_only = getenv("XM_GUESS_FFT") != nullptr;  // tuning switch
-  if (dtype == XM_C64 && ng == kGuessHalf && window && !fft_only) {
+  if (ng == kGuessHalf && window && !fft_only) {
     if (n_batch <= 0) return XM_OK;
     CoarseArgs C;
-    C.in = (const Cx<float>*)in;
+    C.in = in;
     C.window = window;
     C.w1024 = A.aux;
     C.est = est;
@@ -196,14 +196,18 @@ int xm_zf2p_guess_rows(const void* in, int64_t in_stride, const float* window, i
     C.in_stride = in_stride;
     C.n_batch = n_batch;
     C.scale2 = scale * scale;
-    static XmResidency res;
+    static XmResidency res32, res64;
     int resident = 0;
-    rc = xm_resident_blocks(res, k_coarse_mfma, 64 * kCoarseWaves, 0, &resident, st);
+    rc = dtype == XM_C64 ? xm_resident_blocks(res32, k_coarse_mfma<false>, 64 * kCoarseWaves, 0, &resident, st)
+                         : xm_resident_blocks(res64, k_coarse_mfma<true>, 64 * kCoarseWaves, 0, &resident, st);
     if (rc) return rc;
     const long long want = (n_batch + kCoarseWaves - 1) / kCoarseWaves;
     const long long blocks = want < resident ? want : resident;
-    xm_note_kernel("k_coarse_mfma", nullptr, nullptr, kGuessHalf, -1);
-    hipLaunchKernelGGL(k_coarse_mfma, dim3((unsigned)blocks), dim3(64 * kCoarseWaves), 0, st, C);
+    xm_note_kernel("k_coarse_mfma", nullptr, dtype == XM_C64 ? "float" : "double", kGuessHalf, -1);
+    if (dtype == XM_C64)
+      hipLaunchKernelGGL(k_coarse_mfma<false>, dim3((unsigned)blocks), dim3(64 * kCoarseWaves), 0, st, C);
+    else
+      hipLaunchKernelGGL(k_coarse_mfma<true>, dim3((unsigned)blocks), dim3(64 * kCoarseWaves), 0, st, C);
     HIP_TRY(hipGetLastError());
     return XM_OK;
   }
