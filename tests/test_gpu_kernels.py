@@ -531,6 +531,8 @@ def test_coarse_spectra_on_the_matrix_cores_scale_every_row(dev):
     follows; this is its ranking statistic), zero as zero, NaN as NaN, and the launch's key must name the NaN row."""
     import torch
 
+    if os.environ.get("XM_GUESS_FFT"):
+        pytest.skip("XM_GUESS_FFT: the matrix-core kernel is switched off")
     rng = np.random.default_rng(5)
     nb, n_in, n_out = 523, 1024, 2048
     t = np.arange(n_in) * 2e-4
