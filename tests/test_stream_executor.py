@@ -106,8 +106,10 @@ def test_speculative_executor_equals_classic_single_process(monkeypatch):
             assert torch.equal(outs[d], ref_out[d]), (engine, d)
         launched = _stream_double.COUNTS["search_launch"]
         assert (launched >= N_SETS - 5) if engine == "device" else launched == 0, (engine, launched)
-        # launches with an output: one main pass + the winner's fp64 spectrum per dataset, both again for a repair
-        assert _stream_double.COUNTS["guess_rows"] == N_SETS and _stream_double.COUNTS["main"] == 2 * (N_SETS + len(MISSES))
+        # launches with an output: one main pass per dataset (+ the winner's fp64 spectrum with XMRIS_AMD_SLICE=device:
+        # by default the host computes it with the reference's numpy statements), both again for a repair
+        per_set = 1 if pl.slice_on_host() else 2
+        assert _stream_double.COUNTS["guess_rows"] == N_SETS and _stream_double.COUNTS["main"] == per_set * (N_SETS + len(MISSES))
 
 
 @pytest.mark.parametrize("cpus,ranks,gpus,want_device", [(16, 1, 1, False), (1, 1, 1, True), (16, 6, 1, False), (8, 6, 1, False),

@@ -93,6 +93,33 @@ class AutophaseResult:
     hedged: bool = False   # run_stream(speculate=True): the search ran late and was started a second time (see there)
 
 
+def slice_on_host() -> bool:
+    """Where the winning row's spectrum -- the slice the (p0, p1) search runs on (phasing.py:241-247) -- is computed.
+    On the HOST (default): the row comes back as complex128 (64 KiB) and `winner_spectrum` restates the reference's own
+    numpy statements on it, so the search sees the reference's slice BIT FOR BIT (numpy's pocketfft transforms a row of
+    a batch exactly as it transforms the row alone) and, with generations and polish that replicate scipy's, returns
+    the reference's (p0, p1).  `XMRIS_AMD_SLICE=device` keeps rounds 1-3's fp64 kernel (one workgroup, 17 us of the
+    step; its spectrum differs from pocketfft's in the last bit, which the flat landscape of a noise-only dataset
+    amplified to 3e-6 of the spectrum's maximum, profiles/r03/c1_tolerance.txt)."""
+    import os
+
+    return os.environ.get("XMRIS_AMD_SLICE", "host") != "device"
+
+
+def winner_spectrum(plan: "PipelinePlan", row) -> np.ndarray:
+    """zero_fill -> apodize -> ortho FFT -> fftshift of ONE row in numpy, statement for statement what the reference does
+    to every row (fid.py:251 `da.pad(..., constant_values=0)`, fid.py:136-139 `da * weight` with float64 weights --
+    numpy promotes a complex64 FID to complex128 there --, fourier.py:153 `np.fft.fftn(..., norm="ortho")`,
+    fourier.py:31-32 `roll(n // 2)`)."""
+    n_out, n_in, pl = plan.n_out, plan.n_in, plan.pad_left
+    row = np.asarray(row).reshape(-1)[:n_in]
+    buf = np.zeros(n_out, dtype=np.complex128)
+    buf[pl:pl + n_in] = row
+    if plan.window_host is not None:
+        buf = buf * np.asarray(plan.window_host, dtype=np.float64)
+    return np.roll(np.fft.fft(buf, norm="ortho"), n_out // 2)
+
+
 class Selection:
     """Device-side selection stage of autophase, queued without any host synchronisation right behind a
     pre-pass: global arg-max reduction -> gather of the winning FID (row index read from device memory)
@@ -107,7 +134,8 @@ class Selection:
 
         return (torch.empty(1, dtype=real_dtype, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True),
                 torch.empty((1, plan.n_out), dtype=torch.complex128, pin_memory=True),
-                torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device))
+                torch.empty((1, x2.shape[1]), dtype=torch.complex128, device=x2.device),
+                torch.empty((1, x2.shape[1]), dtype=torch.complex128, pin_memory=True))  # (the winning FID, host-slice mode)
 
     def __init__(self, x2, plan: "PipelinePlan", absmax2, argidx, index_from_slice: bool = False, key=None, slot=None,
                  refine=None, blocking=None):
@@ -130,7 +158,11 @@ class Selection:
             if len(pool) <= turn:
                 pool.append(Selection.new_slot(x2, plan, rdt))
             slot = pool[turn]
-        self.h_max, self.h_flat, self.h_slice, x1 = slot
+        self.h_max, self.h_flat, self.h_slice, x1 = slot[:4]
+        self.plan = plan
+        self.h_row = slot[4] if (len(slot) > 4 and slice_on_host()) else None
+        if self.h_row is not None:
+            x1 = self.h_row  # (the kernels below write the winning FID straight into pinned host memory)
         if refine is not None:  # coarse estimates -> exact check of the candidates -> winner decoded + gathered
             window32, est, gkey, wkey, band = refine
             dev.guess_refine(x2, n, window32, est, gkey, wkey, self.h_max, self.h_flat, x1, band=band)
@@ -139,12 +171,18 @@ class Selection:
         else:
             dev.argmax_reduce_async(absmax2, argidx, n, gmax=self.h_max, gflat=self.h_flat)
             dev.gather_row_c128(x2, self.h_flat, n, out=x1)
-        dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
+        if self.h_row is None:
+            dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64, out=self.h_slice)
         self.event = torch.cuda.Event(blocking=aps.scarce_cpus() if blocking is None else blocking)
         self.event.record()
+        self._done = False
 
     def wait(self):
         self.event.synchronize()
+        if self.h_row is not None and not self._done:
+            # (into the pinned slice buffer: the search service, the device search and the polish read it from there)
+            self.h_slice[0].numpy()[:] = winner_spectrum(self.plan, self.h_row[0].numpy())
+            self._done = True
         sl = self.h_slice[0].numpy().copy()
         flat = int(self.h_flat.item())
         if self.index_from_slice:  # index along the axis = first arg-max of the (fp64) winning spectrum
@@ -854,9 +892,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         if trace is not None:  # (the selection stage: exact check of the candidates + the winner's fp64 spectrum)
             ev["sel1"] = torch.cuda.Event(enable_timing=True)
             ev["sel1"].record()
-        if use_dev and exchange is None and j >= cpu_fill:
-            # one rank: the winner needs no exchange -- the search kernel is queued at once, gated on the selection
-            # stage by an event; this thread does not wait for either
+        if use_dev and exchange is None and j >= cpu_fill and not slice_on_host():
+            # one rank, slice computed by the device: the winner needs no exchange -- the search kernel is queued at
+            # once, gated on the selection stage by an event; this thread does not wait for either
             dev_seq[j] = launch_dev_search(j, after=sel[b].event)
 
     # ---- searches on the device (`use_dev`) ------------------------------------------------------------------------
@@ -986,7 +1024,7 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
         ev = events[j]
         ev["t_start"] = time.perf_counter()
         on_dev = use_dev and j >= cpu_fill
-        if on_dev and exchange is None:  # queued behind its selection stage already (guess): nothing to wait for
+        if on_dev and exchange is None and not slice_on_host():  # queued behind its selection stage already (guess)
             ev["t_exchanged"] = ev["t_start"]
             pending[j] = (None, ("dev", dev_seq.pop(j)), None)
             return
@@ -1061,7 +1099,10 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             x1 = inputs[i][row:row + 1].to(torch.complex128)
             if plan.window64 is None:
                 plan.window64 = torch.from_numpy(np.ascontiguousarray(plan.window_host)).to(x1.device, torch.float64)
-            sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out[0].cpu().numpy()
+            if slice_on_host():
+                sl = winner_spectrum(plan, x1[0].cpu().numpy())
+            else:
+                sl = dev.pipeline_fused(x1, n, plan.pad_left, window=plan.window64).out[0].cpu().numpy()
             k = int(np.argmax(np.abs(sl)))
             p0, p1, opt = aps.solve(sl, plan.freq, float(plan.freq[k]), k, iw, method=method, p0_only=p0_only, polish=polish)
             vals = [p0, p1, float(k), float(opt.nfev)]
