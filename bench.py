@@ -348,6 +348,13 @@ def main():
             return shm.broadcast_params(values, owner)
         return sharding.broadcast_params(values, owner, dist, ddev, group=host_group)
 
+    # (XM_BENCH_SOLO_EXCHANGE=1: one rank through the executor's MULTI-rank code path -- trivial exchange / broadcast
+    # callables -- to measure what that path's fixed call order costs on a GPU of its own; a rehearsal switch)
+    solo_exchange = solo_broadcast = None
+    if world == 1 and os.environ.get("XM_BENCH_SOLO_EXCHANGE"):
+        solo_exchange = lambda amax, gflat: (True, gflat, 0)  # noqa: E731
+        solo_broadcast = lambda values, owner: [float(v) for v in values]  # noqa: E731
+
     def run_steps(n_steps, record):
         """n_steps complete passes of the hot path = xmris_amd.pipeline.run_stream over n_steps independent
         datasets (the library's software-pipelined executor: with `overlap` the device runs the pre-pass of
@@ -357,8 +364,8 @@ def main():
         trace = []
         results = pipeline.run_stream([xs[k % len(xs)] for k in range(n_steps)],
                                       [out if k % 2 == 0 else out_b for k in range(n_steps)], plan,
-                                      exchange=exchange if world > 1 else None,
-                                      broadcast=broadcast if world > 1 else None, rank_offset_rows=rank * nv,
+                                      exchange=exchange if world > 1 else solo_exchange,
+                                      broadcast=broadcast if world > 1 else solo_broadcast, rank_offset_rows=rank * nv,
                                       overlap=overlap, trace=trace, speculate=speculate)
         for r in results:
             if speculate:

@@ -1126,9 +1126,11 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
     fast_fill = (exchange is None and not use_dev and overlap and n_sets > 2 and s_ahead >= 2
                  and os.environ.get("XM_FAST_FILL", "1") != "0")
 
-    # (tuning switch, off: measured with four and six ranks sharing the box's one GPU -- 1.61 vs 1.59 and 1.38 vs
-    # 1.40 ms per step, nothing either way; untested where every rank has its own GPU)
-    fill_ramp = overlap and os.environ.get("XM_FILL_RAMP", "0") != "0"
+    # (XM_FILL_RAMP=0: the whole look-ahead in front of the first main pass, rounds 1-3.  Measured through the multi-rank
+    # code path on a GPU of its own -- `bench.py` with XM_BENCH_SOLO_EXCHANGE=1, driver command, four rounds,
+    # profiles/r04/fill.txt: 1.302 -> 1.244 ms per step, i.e. what one rank reaches with the event-driven fill
+    # (1.248); four and six ranks SHARING the box's one GPU: 1.61 vs 1.59 and 1.38 vs 1.40, nothing either way.)
+    fill_ramp = overlap and os.environ.get("XM_FILL_RAMP", "1") != "0"
 
     # searches started beside the pipeline-filling one (it has the whole team for its millisecond; the others have
     # device periods of slack and start right behind it) -- tuning switch, A/B in profiles/r04/fill.txt
