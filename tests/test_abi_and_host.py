@@ -521,6 +521,30 @@ def test_lean_polish_is_scipys_minimize_to_the_bit(oracle, monkeypatch, fg):
     assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev
 
 
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+@pytest.mark.parametrize("n_in,target,lb", [(1024, 2048, 5.0), (1536, 1536, 5.0), (1972, 4096, 0.0), (4096, 8192, 12.5), (1000, 1024, 3.0)])
+def test_winner_spectrum_is_the_reference_slice_bit_for_bit(oracle, dtype, n_in, target, lb):
+    """`pipeline.winner_spectrum` -- the slice the (p0, p1) search runs on -- restates fid.py:251, fid.py:136-139,
+    fourier.py:153 and fourier.py:31-32 on ONE row; it must equal, bit for bit, the row the oracle (= the reference's
+    statements on the whole batch) slices out of its spectra: numpy's FFT of a row of a batch and of the row alone are
+    the same bits, complex64 storage is promoted at the apodisation as numpy promotes it; zero fill to 2x, to an odd
+    ratio, none; lb = 0 (all-ones weights)."""
+    import torch
+
+    from xmris_amd import pipeline as pl
+
+    rng = np.random.default_rng(n_in + target)
+    t = 3e-4 + np.arange(n_in) * 2e-4
+    x = (rng.standard_normal((7, n_in)) + 1j * rng.standard_normal((7, n_in))).astype(dtype)
+    x[4] *= 3.0
+    ref, info = oracle.pipeline_values(x, t, target, lb, peak_width=100, solve=False)
+    row = info["flat_idx"] // info["freq"].size
+    plan = pl.make_plan(torch.from_numpy(x), t, target, lb)
+    got = pl.winner_spectrum(plan, x[row].astype(np.complex128))
+    assert got.dtype == np.complex128 and np.array_equal(got, info["slice"])
+    assert int(np.argmax(np.abs(got))) == info["target_idx"]
+
+
 def test_polish_workers_never_make_a_caller_wait_for_their_start(oracle):
     """`autophase_solver.PolishWorkers`: a request submitted before any worker has reported ready is polished by the
     future's own thread; once the workers are up they answer with the same (x, fun, nfev) to the bit -- the polish is
