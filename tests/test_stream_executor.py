@@ -20,6 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N_IN, N_OUT, LB, DT = 1024, 2048, 5.0, 1.0 / 5000.0
 ROWS_PER_RANK, N_SETS = 8, 14
 MISSES = {4: (2, 6), 9: (5, 3)}  # dataset -> (rank of the burst row = the true arg-max, rank of the coarse winner)
+if os.environ.get("XM_TEST_MISSES"):  # "dataset:true_rank:coarse_rank,..." -- another placement (see the last test)
+    MISSES = {int(a): (int(b), int(c)) for a, b, c in (tok.split(":") for tok in os.environ["XM_TEST_MISSES"].split(","))}
 
 
 def _free_port():
@@ -229,3 +231,16 @@ def test_world_8_speculative_executor(monkeypatch, engine):
             assert counts["search_launch"] == 0
     if engine == "host":
         assert hedged >= 1  # the late search of dataset 7
+
+
+def test_world_8_with_the_misses_inside_the_pipeline_fill():
+    """The same eight-rank run with the two wrongly guessed datasets at the very START of the call (datasets 0 and 1): the
+    repairs then fall into the phase in which the look-ahead is still being built up (`fill_ramp`: three searches before
+    the first main pass, three more with every dataset), where the order of exchange / broadcast calls differs from
+    the steady state's.  Runs this module's world-8 test (host engine) in a child pytest with XM_TEST_MISSES set."""
+    import subprocess
+
+    env = dict(os.environ, XM_TEST_MISSES="0:2:6,1:5:3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "test_world_8_speculative_executor and host",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
