@@ -5,9 +5,11 @@ One "step" = one full pass of  zero_fill -> apodize_exp -> to_spectrum -> autoph
 synthetic batch that is already resident in HBM, run by the library's streaming executor
 `xmris_amd.pipeline.run_stream`.  Default (speculative) schedule, per step:
     guess stage: coarse spectra of every row (`xm_guess_rows`: the first 512 windowed samples on a 1024-bin grid,
-    one wave per row) -> exact transform of every row whose estimate lies within a band of the largest
-    (`xm_guess_refine`, branch and bound; the last workgroup gathers the winning FID as complex128)
- -> that row's spectrum recomputed in complex128 (one workgroup, written to pinned host memory)
+    one wave per row, on the matrix cores: `k_coarse_mfma`) -> exact transform of every row whose estimate lies
+    within a band of the largest (`xm_guess_refine`, branch and bound; the last workgroup writes the winning FID as
+    complex128 into pinned host memory)
+ -> that ONE row's spectrum computed by the host with the reference's numpy statements (`pipeline.winner_spectrum`:
+    the slice the search runs on is the reference's bit for bit)
  -> the (p0, p1) search on it: scipy's differential evolution restated natively, on native host threads of the
     library (`xm_hostsearch_submit`) or, where the host is short of cores, as one workgroup on a reserved CU
     (`xm_search_launch`); the polish follows the reference's route wherever it iterates
