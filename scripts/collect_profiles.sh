@@ -66,7 +66,7 @@ if has labs; then
     echo "-- XMRIS_AMD_POLISH=native: round 3's native polish"; XMRIS_AMD_POLISH=native NSETS=16 python3 scripts/time_hetero.py 2>/dev/null | grep "^rep";
   } > $out/hetero_polish.txt
   python3 scripts/time_accessor_host_path.py > $out/host_path.txt 2>/dev/null
-  python3 scripts/c1_tolerance.py > $out/c1_tolerance.txt 2>/dev/null
+  python3 tests/tool_c1_tolerance.py > $out/c1_tolerance.txt 2>/dev/null
   python3 scripts/check_device_search.py > $out/device_search.txt 2>/dev/null || true   # (two degenerate slices diverge: exit 1)
   python3 scripts/time_zf_apod.py > $out/zf_apod.txt 2>/dev/null
   bash scripts/ab_search_engines.sh > $out/search_engines.txt 2>/dev/null; rm -f gpurun_out/ab_*.json gpurun_out/ab.err

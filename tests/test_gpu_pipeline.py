@@ -103,7 +103,7 @@ def test_c1_readme_quickstart(mods, oracle, dtype):
 
 
 def test_autophase_parameters_are_the_oracles_on_random_datasets():
-    """`scripts/sweep_autophase_exact.py` (seed 0, 14 datasets of its five families -- a few lines, many lines, noise only, one
+    """`tests/tool_sweep_autophase_exact.py` (seed 0, 14 datasets of its five families -- a few lines, many lines, noise only, one
     voxel far brighter, short FIDs incl. chirp-z lengths and no zero fill -- in both storage precisions): (p0, p1) of
     the fused path are the CPU oracle's on the same array (|dp| < 1e-9 degrees; measured: exactly equal in 80 of 80,
     profiles/r04/autophase_exact_sweep.txt) and the phased spectra sit at the storage floor.  Reference statement served:
@@ -113,7 +113,7 @@ def test_autophase_parameters_are_the_oracles_on_random_datasets():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "sweep_autophase_exact.py"), "0", "14"], cwd=root,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tool_sweep_autophase_exact.py"), "0", "14"], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("case")]

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE configs[0] (README quick start: 5 x 1024 noise FIDs, zero_fill(2048), apodize_exp(lb=5), to_spectrum,
+"""(A measurement tool that uses the CPU oracle as its checker: it lives under tests/, the only place besides
+__graft_entry__.smoke() and bench.py's cpu_baseline leg that may import oracle/.)
+BASELINE configs[0] (README quick start: 5 x 1024 noise FIDs, zero_fill(2048), apodize_exp(lb=5), to_spectrum,
 autophase) end to end on the GPU against the CPU oracle: |dp0|, |dp1| and the relative error of the phased spectra for
 the injected-parameter route and the own solve with each polish mode ("exact" is the default everywhere since round 4),
 through the one-dataset call and through the streaming executor, both storage precisions.  Output kept under profiles/ (north_star: <= 1e-5)."""

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""How often are (p0, p1) of the HIP path EXACTLY the CPU oracle's?  Random datasets of several families (a few damped
+"""(A measurement tool that uses the CPU oracle as its checker: it lives under tests/, the only place besides
+__graft_entry__.smoke() and bench.py's cpu_baseline leg that may import oracle/.)
+How often are (p0, p1) of the HIP path EXACTLY the CPU oracle's?  Random datasets of several families (a few damped
 lines, many lines, noise only, one voxel far brighter, short and long FIDs), both storage precisions, the fused
 zero_fill -> apodize_exp -> to_spectrum -> autophase through `pipeline.run` against `oracle.pipeline_values` on the SAME
 array.  Since round 4 the search runs on the reference's slice bit for bit (`pipeline.winner_spectrum`), its generations
 replicate scipy's and its polish follows scipy's route; what could still differ is a generation's accept / reject
 decision on a near-tie (the native objective differs from numpy's in the last bits).  Prints one line per case and a
-summary.  usage: sweep_autophase_exact.py [seed=0] [cases=40]"""
+summary.  usage: tool_sweep_autophase_exact.py [seed=0] [cases=40]"""
 import os
 import sys
 import time

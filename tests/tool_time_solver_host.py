@@ -1,4 +1,6 @@
-"""Host-only timing of xm_solver_de on a benchmark-like slice (no GPU needed).
+"""(A measurement tool that uses the CPU oracle as its checker: it lives under tests/, the only place besides
+__graft_entry__.smoke() and bench.py's cpu_baseline leg that may import oracle/.)
+Host-only timing of xm_solver_de on a benchmark-like slice (no GPU needed).
 XM_SOLVER_BATCH=1 reproduces the one-trial-per-hand-off schedule."""
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
