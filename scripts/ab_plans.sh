@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage (GPU box): bash scripts/ab_plans.sh -- same-box A/B of the 3 * 2^k plan rows (xm_plans.h, XM_ALT_PLANS):
-# the shipped build against xmris_amd/libxmris_hip_alt{1,2}.so (build them with
-#   make -C xmris_amd/csrc OUT=../libxmris_hip_alt1.so BUILD=../../build/alt1 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-comment -DXM_ALT_PLANS=1")
+# usage (GPU box): bash scripts/ab_plans.sh -- same-box A/B of builds of the library that differ in their 3 * 2^k plan rows
+# (xm_plans.h), run through XMRIS_AMD_LIB: the shipped build against xmris_amd/libxmris_hip_alt{1,2}.so when they exist.
+# The builds measured in profiles/r04/ab_plans.txt came from a temporary -DXM_ALT_PLANS switch in xm_plans.h (rows listed in
+# that file's header); the outcome -- only 1536 gains, and only for the plain transform -- is `Plan1536Wide` there.
 set -e
 here=$(cd "$(dirname "$0")/.." && pwd)
 for v in shipped alt1 alt2; do
