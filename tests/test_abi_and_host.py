@@ -521,6 +521,35 @@ def test_lean_polish_is_scipys_minimize_to_the_bit(oracle, monkeypatch, fg):
     assert np.array_equal(fb.x, ref.x) and fb.nfev == ref.nfev
 
 
+def test_coarse_spectra_factorisation_used_by_the_matrix_core_kernel():
+    """The algebra of `csrc/xm_coarse.h` in numpy: the 1024-bin DFT of 512 samples as two 32-point stages with the
+    kernel's index maps -- n = 32 n1 + n2 (n1 < 16), k = k1 + 32 k2; D1[n2, k1] = sum_n1 x[32 n1 + n2] W32^(n1 k1),
+    Z = D1 * W1024^(n2 k1), X[k1 + 32 k2] = sum_n2 W32^(n2 k2) Z[n2, k1] -- including the PERMUTED contraction order in
+    which an MFMA accumulator tile presents its rows to the next product (element j of lane half h at k-step s is row
+    16 s + 8 (j >> 2) + 4 h + (j & 3)): summing the second stage in that order, with the constant operand permuted the
+    same way, must give the plain DFT."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(512) + 1j * rng.standard_normal(512)
+    ref = np.fft.fft(x, n=1024)
+    w32 = lambda m: np.exp(-2j * np.pi * (m % 32) / 32)  # noqa: E731
+    w1024 = lambda m: np.exp(-2j * np.pi * (m % 1024) / 1024)  # noqa: E731
+    n1, n2, k1, k2 = np.arange(16), np.arange(32), np.arange(32), np.arange(32)
+    a1 = x.reshape(16, 32).T                                   # A1[n2, n1] = x[32 n1 + n2]
+    d1 = a1 @ w32(np.outer(n1, k1))                            # D1[n2, k1]
+    z = d1 * w1024(np.outer(n2, k1))
+    d2 = np.zeros((32, 32), dtype=complex)                     # D2[k2, k1]
+    for s in range(2):                                         # two k-steps of 16, in the accumulator tile's row order
+        for h in range(2):
+            for j in range(8):
+                row = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+                d2 += np.outer(w32(row * k2), z[row])
+    got = np.empty(1024, dtype=complex)
+    got[(k1[None, :] + 32 * k2[:, None])] = d2
+    assert np.allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    rows = sorted(16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8))
+    assert rows == list(range(32))  # every row of Z exactly once
+
+
 @pytest.mark.parametrize("dtype", ["complex128", "complex64"])
 @pytest.mark.parametrize("n_in,target,lb", [(1024, 2048, 5.0), (1536, 1536, 5.0), (1972, 4096, 0.0), (4096, 8192, 12.5), (1000, 1024, 3.0)])
 def test_winner_spectrum_is_the_reference_slice_bit_for_bit(oracle, dtype, n_in, target, lb):

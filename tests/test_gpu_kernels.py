@@ -524,7 +524,8 @@ def test_guess_rows_and_refine(dev, nb, n_in, n_out, dtype):
     assert int(gflat.item()) == (3 if fooled else true_row) * n_out
 
 
-def test_coarse_spectra_on_the_matrix_cores_scale_every_row(dev):
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_coarse_spectra_on_the_matrix_cores_scale_every_row(dev, dtype):
     """`k_coarse_mfma` feeds fp16 operands to the matrix cores behind a power-of-two scale PER ROW: rows of ADC counts
     (1e5), volts (1e-6), very large and very small numbers, a zero row and a NaN row in one launch must each come out
     within 2e-3 of the fp64 DFT of their first 512 windowed samples (phasing.py:229 is served by the exact check that
@@ -543,7 +544,7 @@ def test_coarse_spectra_on_the_matrix_cores_scale_every_row(dev):
     mag[:6] = [1e5, 1e-6, 3e15, 2e-15, 1.0, 1.0]
     x *= mag[:, None]
     x[4] = 0.0
-    x = x.astype(np.complex64)
+    x = x.astype(dtype)
     w = np.exp(-np.pi * 5.0 * np.arange(n_out) * 2e-4)
     xc = x[:, :512].astype(np.complex128) * w[:512]
     ref = (np.abs(np.fft.fft(xc, n=1024, axis=1)) ** 2).max(axis=1) / n_out
