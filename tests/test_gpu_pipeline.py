@@ -102,6 +102,39 @@ def test_c1_readme_quickstart(mods, oracle, dtype):
     _check(mods, oracle, x, t, 2048, 5.0, dtype)  # pure noise, a flat objective: (p0, p1) still equal the oracle's
 
 
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_streaming_executor_returns_the_oracles_parameters(mods, oracle, dtype):
+    """`run_stream(speculate=True)` -- the executor `bench.py` times -- over eight DISTINCT datasets (own noise, the
+    brightest voxel somewhere else each time, two of them noise only, one guessed wrong and repaired): every dataset's
+    (p0, p1), pivot and flat index equal the CPU oracle's on the same array (|dp| < 1e-9 degrees; the search runs on the
+    reference's slice bit for bit) and every phased spectrum sits at the storage floor."""
+    import torch
+
+    dev, pipe = mods
+    nv, nt, target = 64, 1024, 2048
+    sets = []
+    for k in range(8):
+        x, t = _three_peak(nv, nt, 2e-4, seed=300 + k)
+        x[(7 * k + 3) % nv] *= 1.7
+        if k in (2, 5):  # noise only: the flat landscape
+            rng = np.random.default_rng(900 + k)
+            x = rng.standard_normal((nv, nt)) + 1j * rng.standard_normal((nv, nt))
+        if k == 6:  # a late burst: invisible to the coarse spectra, the tallest line of the dataset -> repaired
+            x[11] = _late_burst(t, 60.0)
+        sets.append(x.astype(dtype))
+    refs = [oracle.pipeline_values(x, t, target, 5.0, peak_width=100) for x in sets]
+    xd = [dev.to_device(x) for x in sets]
+    plan = pipe.make_plan(xd[0], t, target, 5.0)
+    outs = [torch.empty((nv, target), dtype=xd[0].dtype, device="cuda") for _ in sets]
+    got = pipe.run_stream(xd, outs, plan, speculate=True)
+    torch.cuda.synchronize()
+    assert [r.speculation for r in got] == ["repaired" if k == 6 else "hit" for k in range(8)]
+    for k, (r, (ref, info)) in enumerate(zip(got, refs)):
+        assert (r.flat_index, r.pivot) == (info["flat_idx"], info["pivot"]), k
+        assert abs(r.p0 - info["p0"]) < 1e-9 and abs(r.p1 - info["p1"]) < 1e-9, (k, r.p0 - info["p0"], r.p1 - info["p1"])
+        assert _relerr(outs[k].cpu().numpy(), ref) < (1e-6 if dtype == "complex64" else 1e-12), k
+
+
 def test_autophase_parameters_are_the_oracles_on_random_datasets():
     """`tests/tool_sweep_autophase_exact.py` (seed 0, 14 datasets of its five families -- a few lines, many lines, noise only, one
     voxel far brighter, short FIDs incl. chirp-z lengths and no zero fill -- in both storage precisions): (p0, p1) of
