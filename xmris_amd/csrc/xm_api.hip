@@ -256,7 +256,7 @@ static int launch_zf_apod(const void* in, int64_t in_stride, void* out, const vo
   A.n_in = n_in;
   A.n_out = n_out;
   A.pad_left = pad_left;
-  const size_t lds = (size_t)n_out * sizeof(TO);
+  const size_t lds = (size_t)(n_in < n_out ? n_in : n_out) * sizeof(TO);  // (the window over the acquired samples)
   const size_t esz = sizeof(Cx<TI>);
   // 16-byte lanes: rows of both arrays on 16-byte boundaries, and (8-byte elements) whole pairs inside the samples
   const bool vec = (reinterpret_cast<size_t>(in) % 16 == 0) && (reinterpret_cast<size_t>(out) % 16 == 0) &&
@@ -269,6 +269,13 @@ static int launch_zf_apod(const void* in, int64_t in_stride, void* out, const vo
     static XmResidency res;
     rc = xm_resident_blocks(res, k_zf_apod<TI, TO, true>, 256, lds, &resident, st);
     if (rc) return rc;
+    // Few workgroups per CU: measured on 65,536 x 4096 -> 8192 complex64 with 1 / 2 / 3 / 4 / 5 per CU: 3.27 / 5.40 /
+    // 5.63 / 5.34 / 5.33 TB/s, with ten 4.73; rows of complex128 out (twice the bytes per workgroup and step): 2 / 3 / 4
+    // per CU 5.48 / 5.31 / 5.06, promoted complex64 -> complex128 4.77 / 4.21 / 3.96 (profiles/r04/zf_apod.txt) -- a
+    // streaming copy wants few, deep streams: three for 8-byte outputs, two for 16-byte ones
+    static const int wgs_env = getenv("XM_ZFAPOD_WGS") ? atoi(getenv("XM_ZFAPOD_WGS")) : (sizeof(TO) == 4 ? 3 : 2);  // tuning switch
+    int cus = 0;
+    if (wgs_env > 0 && xm_stream_cu_count(st, &cus) == XM_OK && cus > 0 && resident > wgs_env * cus) resident = wgs_env * cus;
     const long long blocks = n_batch < resident ? n_batch : resident;
     xm_note_kernel("k_zf_apod", nullptr, sizeof(TI) == 4 ? (sizeof(TO) == 4 ? "float, float" : "float, double") : "double, double", 1, -1);
     hipLaunchKernelGGL((k_zf_apod<TI, TO, true>), dim3((unsigned)blocks), dim3(256), lds, st, A);

@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void k_zf_apod(ZfApodArgs<TI, TO> A) {
   constexpr int NT = 256;
   constexpr int EPL = VEC ? (int)(16 / sizeof(Cx<TI>)) : 1;  // input elements per lane and step (2 x c64, 1 x c128)
   extern __shared__ __attribute__((aligned(16))) char xm_smem[];
-  TO* wl = reinterpret_cast<TO*>(xm_smem);  // the window, n_out weights
+  TO* wl = reinterpret_cast<TO*>(xm_smem);  // the window over the ACQUIRED samples only (n_in weights from pad_left on:
+                                            // the padding needs none) -- 8192 doubles would allow two workgroups per CU
   __shared__ long long ticket[2];
   const int t = (int)threadIdx.x;
-  for (int j = t; j < A.n_out; j += NT) wl[j] = A.window[j];
+  for (int j = t; j < A.n_in && A.pad_left + j < A.n_out; j += NT) wl[j] = A.window[A.pad_left + j];
   long long row = blockIdx.x;  // the first round is static, then tickets
   if (t == 0) ticket[0] = (long long)gridDim.x + (long long)atomicAdd(A.queue, 1u);
   __syncthreads();
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_zf_apod(ZfApodArgs<TI, TO> A) {
         const int ke = k + e;
         const bool in_range = ke >= 0 && ke < A.n_in && j0 + e < A.n_out;
         const Cx<TI> v = in_range ? irow[ke] : mk<TI>(TI(0), TI(0));
-        const TO w = in_range ? wl[j0 + e] : TO(0);
+        const TO w = in_range ? wl[ke] : TO(0);
         y[e] = in_range ? mk<TO>((TO)v.re * w, (TO)v.im * w) : mk<TO>(TO(0), TO(0));  // the padding is +0
       }
       if constexpr (VEC) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_zf_apod(ZfApodArgs<TI, TO> A) {
             Cx<TO> y[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-              const TO w = wl[j0 + u * per_step + e];
+              const TO w = wl[k + u * per_step + e];
               y[e] = mk<TO>((TO)v[u][e].re * w, (TO)v[u][e].im * w);  // complex times real: two products, as numpy's
             }
             store_vec(orow + j0 + u * per_step, y);
