@@ -1,5 +1,6 @@
 // Host-side declarations shared by the translation units of libxmris_hip.so.
 #pragma once
+#include <cstdlib>
 #include "../../include/xmris_hip.h"
 #include "xm_common.h"
 
@@ -96,6 +97,10 @@ int xm_resident_blocks(XmResidency& r, K kern, int nt, size_t lds, int* out, hip
     }
     per_cu = r.blocks[dev];
   }
+  // (tuning switch XM_RESIDENT_CAP=<workgroups per CU>: an upper bound for every persistent grid -- the sweep that found
+  // k_zf_apod's three per CU, profiles/r04/zf_apod.txt, applied to the other kernels: profiles/r04/resident_cap.txt)
+  static const int cap_env = getenv("XM_RESIDENT_CAP") ? atoi(getenv("XM_RESIDENT_CAP")) : 0;
+  if (cap_env > 0 && per_cu > cap_env) per_cu = cap_env;
   int cus = 0;
   const int rc = xm_stream_cu_count(st, &cus);
   if (rc) return rc;
