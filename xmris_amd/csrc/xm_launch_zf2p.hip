@@ -31,6 +31,13 @@ int launch_mode(PipeArgs<T> A, hipStream_t st) {
   int resident = 0;
   rc = xm_resident_blocks(res, k_zf2p<PL, MODE, OPT>, PL::NT, lds, &resident, st);
   if (rc) return rc;
+  if constexpr ((MODE & ZF2_WRITE) != 0 && PL::N == 2048) {
+    // BASELINE configs[1]'s main pass (2048 -> 4096): TWO workgroups per CU, as the 4096-point plan has by its LDS -- with
+    // the four that fit 0.170 ms, with three 0.164, with two 0.156 (4.73 -> 5.17 TB/s; profiles/r04/resident_cap.txt).
+    // A streaming kernel wants few, deep streams (k_zf_apod: three per CU).
+    int cus = 0;
+    if (xm_stream_cu_count(st, &cus) == XM_OK && cus > 0 && resident > 2 * cus) resident = 2 * cus;
+  }
   // rows per ticket: about 96 KiB of traffic per chunk (the hot shape's row: 1 -- measured: 2 rows per ticket cost it
   // 12 %), so that a launch at full speed draws at most ~60 of the ~90 tickets per microsecond one counter sustains
   const long long row_bytes = (long long)sizeof(Cx<T>) * ((long long)A.n_in + (A.out ? 2 * PL::N : 0));
