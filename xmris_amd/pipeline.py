@@ -836,9 +836,9 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
             if blocking:
                 nap = min(1e-4, nap + 1e-5)
                 time.sleep(nap)
-            else:
-                time.sleep(0)  # (hands the interpreter lock to a waiting thread -- a polish helper's pipe I/O -- at once
-                               # instead of after the 5 ms switch interval a spinning thread would hold it for)
+            # (no time.sleep(0) here to hand over the interpreter lock: tried at the end of round 4 -- with the search teams
+            # spinning on every core of the quota a yielding launch thread lost its CPU for 2-3 ms at a time, K = 20
+            # went from 1.22 to 1.39-1.51 ms per step in two collections)
         r = dev.read_search_record(rec)
         hist = fill_hist if i == 0 else run_hist
         hist.append(1e-6 * r["t_us"][5])
@@ -1177,8 +1177,8 @@ def _spec_loop(inputs, outputs, plan, exchange, broadcast, rank_offset_rows, ove
                 if nxt <= guessed and sel[nxt % ring].event.query():
                     started = nxt
                     start_search(nxt)
-                elif not more_guesses:
-                    time.sleep(2e-5 if blocking else 0)  # (0: only yields the interpreter lock)
+                elif blocking and not more_guesses:
+                    time.sleep(2e-5)
         # (several ranks -- where the order of the exchange calls may not depend on anything a rank observes -- and the
         # other engines: the look-ahead is built up over the first datasets, three searches before the first main pass
         # and three more with every dataset, instead of all of it in front of the first main pass)
